@@ -1,0 +1,391 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference); the GPU box never
+runs this.  Only *data* is written: mapped-program text as printed by the
+reference (`LutExecEnv.print(show_outputs=True)` fbs_exec_env.py:158-168 and
+`write_lbf` :170-206), the `stats()` dict (:245-276), the seed-42 harness
+inputs (map_circuit.py:137-139) and the outputs of both cleartext evaluators
+(`BitExecEnv.eval` bit_exec_env.py:173-194, `LutExecEnv.eval`
+fbs_exec_env.py:208-229).  No reference source text is stored.
+
+Usage (from anywhere):
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/capture_reference.py [--big] [--only NAME]
+
+Fixture format: gzip'd JSON, one file per case, see `dump_case`.
+"""
+import argparse
+import gzip
+import io
+import json
+import logging
+import os
+import sys
+import time
+
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "fbs_mapper"))
+sys.path.insert(0, os.path.join(REF, "experiments"))
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+
+_argv = sys.argv
+sys.argv = ["capture"]
+import bit_exec_env  # noqa: E402
+import fbs_exec_env  # noqa: E402
+import map_to_fbs  # noqa: E402
+import generate_benchmarks as gb  # noqa: E402
+sys.argv = _argv
+
+# generate_benchmarks imports `fbs_mapper.bit_exec_env` (a different module
+# object from the top-level `bit_exec_env` the mappers match on); make every
+# circuit with the class the mappers pattern-match against.
+BitExecEnv = bit_exec_env.BitExecEnv
+LutExecEnv = fbs_exec_env.LutExecEnv
+
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+T_SAMPLES = 1000
+
+
+# --------------------------------------------------------------------------
+# circuit sources
+# --------------------------------------------------------------------------
+def gen_from_reference(fn):
+    def build():
+        env = BitExecEnv()
+        gb.Bit.set_env(env)
+        fn()
+        env.remove_dangling_nodes()
+        return env
+    return build
+
+
+def _xor(env, a, b):
+    return env.op_lut([a, b], [0, 1, 1, 0])
+
+
+def _and(env, a, b):
+    return env.op_lut([a, b], [0, 0, 0, 1])
+
+
+def _or(env, a, b):
+    return env.op_lut([a, b], [0, 1, 1, 1])
+
+
+def ripple_adder(bits):
+    """`bits`-bit ripple-carry adder (stand-in for EPFL adder.blif)."""
+    def build():
+        env = BitExecEnv()
+        a = [env.input(f"a{i}") for i in range(bits)]
+        b = [env.input(f"b{i}") for i in range(bits)]
+        carry = None
+        for i in range(bits):
+            p = _xor(env, a[i], b[i])
+            if carry is None:
+                s = p
+                carry = _and(env, a[i], b[i])
+            else:
+                s = _xor(env, p, carry)
+                g = _and(env, a[i], b[i])
+                t = _and(env, p, carry)
+                carry = _or(env, g, t)
+            env.output(f"s{i}", s)
+        env.output("cout", carry)
+        env.remove_dangling_nodes()
+        return env
+    return build
+
+
+def array_multiplier(bits):
+    """bits x bits unsigned array multiplier (stand-in for ISCAS85 c6288)."""
+    def build():
+        env = BitExecEnv()
+        a = [env.input(f"a{i}") for i in range(bits)]
+        b = [env.input(f"b{i}") for i in range(bits)]
+
+        def full_add(x, y, c):
+            p = _xor(env, x, y)
+            s = _xor(env, p, c)
+            co = _or(env, _and(env, x, y), _and(env, p, c))
+            return s, co
+
+        def half_add(x, y):
+            return _xor(env, x, y), _and(env, x, y)
+
+        # row 0 partial products
+        acc = [_and(env, a[i], b[0]) for i in range(bits)]
+        env.output("p0", acc[0])
+        acc = acc[1:]          # weights 1..bits-1 relative to next row
+        top = None             # carry-out column of the previous row
+        for j in range(1, bits):
+            pp = [_and(env, a[i], b[j]) for i in range(bits)]
+            new = []
+            carry = None
+            for i in range(bits):
+                x = pp[i]
+                y = acc[i] if i < len(acc) else top
+                if y is None:
+                    if carry is None:
+                        s = x
+                    else:
+                        s, carry = half_add(x, carry)
+                elif carry is None:
+                    s, carry = half_add(x, y)
+                else:
+                    s, carry = full_add(x, y, carry)
+                new.append(s)
+            env.output(f"p{j}", new[0])
+            acc = new[1:]
+            top = carry
+        for i, w in enumerate(acc):
+            env.output(f"p{bits + i}", w)
+        env.output(f"p{2 * bits - 1}", top)
+        env.remove_dangling_nodes()
+        return env
+    return build
+
+
+def trivium_stream_short(iters):
+    """First `iters` steps of the reference's trivium_stream_v2 netlist
+    (generate_benchmarks.py:389-414 builds 1152 steps; that takes ~26 min to
+    map here, so a short prefix is the every-day wide fixture)."""
+    def build():
+        env = BitExecEnv()
+        gb.Bit.set_env(env)
+        s = [None] + [gb.Bit.input(f"s{k}") for k in range(1, 289)]
+        for i in range(iters):
+            r, t1, t2, t3 = gb.TriviumIter.iter_v2(s)
+            r.output(f"r{i}")
+            s[1:94] = [t3, *s[1:93]]
+            s[94:178] = [t1, *s[94:177]]
+            s[178:289] = [t2, *s[178:288]]
+        env.remove_dangling_nodes()
+        return env
+    return build
+
+
+SMALL_GENERATORS = {
+    "ascon_lut": gb.ascon_lut,
+    "aes_sbox": gb.aes_sbox,
+    "simon_iter": gb.simon_iter,
+    "2_input_gates": gb._2_input_gates,
+    "full_adder": gb.full_adder_bench,
+    "half_adder": gb.half_adder_bench,
+    "aoi21": gb.aoi21_bench,
+    "oai21": gb.oai21_bench,
+    "kreyvium_iter_v1": gb.KreyviumIter.kreyvium_iter_v1,
+    "kreyvium_iter_v2": gb.KreyviumIter.kreyvium_iter_v2,
+    "kreyvium_iter_v3": gb.KreyviumIter.kreyvium_iter_v3,
+    "trivium_iter_v1": gb.TriviumIter.trivium_iter_v1,
+    "trivium_iter_v2": gb.TriviumIter.trivium_iter_v2,
+    "trivium_iter_v3": gb.TriviumIter.trivium_iter_v3,
+}
+
+
+# --------------------------------------------------------------------------
+# dumping
+# --------------------------------------------------------------------------
+def pack_bits(arr):
+    arr = np.asarray(arr).reshape(-1)
+    return np.packbits(arr.astype(np.uint8)).tobytes().hex()
+
+
+def encode_values(v):
+    """Outputs are normally bit vectors; constants come back as python ints and
+    the LutExecEnv demo has a 3-valued table."""
+    if isinstance(v, (int, np.integer)):
+        return {"const": int(v)}
+    v = np.asarray(v).reshape(-1)
+    if v.size and v.min() >= 0 and v.max() <= 1:
+        return {"bits": pack_bits(v), "n": int(v.size)}
+    return {"ints": [int(x) for x in v]}
+
+
+def harness_inputs(names, T):
+    # map_circuit.py:137-139 -- legacy RandomState, one draw per input, in order
+    np.random.seed(42)
+    return {name: np.random.randint(0, 2, (T)) for name in names}
+
+
+def dump_case(name, lut_env, input_vals, expect_bit, meta):
+    buf = io.StringIO()
+    lut_env.print(show_outputs=True, os=buf)
+    fbs_text = buf.getvalue()
+    buf = io.StringIO()
+    try:
+        lut_env.write_lbf(os=buf)
+        lbf_text = buf.getvalue()
+    except AssertionError:
+        lbf_text = None
+    out_lut = lut_env.eval(input_vals)
+    if expect_bit is not None:
+        assert expect_bit.keys() == out_lut.keys()
+        for k in expect_bit:
+            assert np.all(expect_bit[k] == out_lut[k]), (name, k)
+    input_names = [i.name for i in lut_env.instructions
+                   if isinstance(i, LutExecEnv.Input)]
+    rec = dict(
+        name=name,
+        meta=meta,
+        stats={k: int(v) for k, v in lut_env.stats().items()},
+        max_val={k: int(v) for k, v in lut_env.max_val.items()},
+        fbs=fbs_text,
+        lbf=lbf_text,
+        program_inputs=input_names,
+        harness_inputs=list(input_vals.keys()),
+        T=int(len(np.asarray(next(iter(input_vals.values()))).reshape(-1))) if input_vals else 0,
+        inputs={k: encode_values(np.asarray(v)) for k, v in input_vals.items()},
+        outputs={str(k): encode_values(v) for k, v in out_lut.items()},
+        outputs_bitenv=None if expect_bit is None else
+        {str(k): encode_values(v) for k, v in expect_bit.items()},
+    )
+    path = os.path.join(OUT_DIR, name + ".json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(rec, sort_keys=True).encode())
+    return path
+
+
+def make_mapper(mapper, fbs_size, strict, max_tt=16):
+    if mapper == "basic":
+        return map_to_fbs.MapToFBSBasic()
+    max_fbs = fbs_size if strict else 2 * fbs_size      # map_circuit.py:117-122
+    return map_to_fbs.MapToFBSHeur(fbs_size=fbs_size, max_fbs_size=max_fbs,
+                                   max_truth_table_size=max_tt, cone_merger=mapper)
+
+
+def map_and_dump(case, build, mapper, fbs_size, strict=False, T=T_SAMPLES):
+    bit_env = build()
+    input_vals = harness_inputs([i.name for i in bit_env.inputs], T)
+    out_bit = bit_env.eval(input_vals)
+    t0 = time.time()
+    tag = f"{case}__{mapper}_p{fbs_size}" + ("_strict" if strict else "")
+    try:
+        lut_env = make_mapper(mapper, fbs_size, strict).map(bit_env)
+    except Exception as e:     # map_circuit.py:146-150: the CLI logs and exits; no output is produced
+        print(f"{tag}: mapper failed ({type(e).__name__}) -- no fixture", flush=True)
+        return
+    lut_env.remove_dangling_nodes()
+    dt = time.time() - t0
+    meta = dict(circuit=case, mapper=mapper, fbs_size=fbs_size, strict=bool(strict),
+                max_fbs_size=fbs_size if strict else 2 * fbs_size, map_seconds=round(dt, 2))
+    path = dump_case(tag, lut_env, input_vals, out_bit, meta)
+    print(f"{tag}: {lut_env.stats()}  map {dt:.1f}s -> {os.path.basename(path)}", flush=True)
+
+
+# --------------------------------------------------------------------------
+# hand-made programs through the reference builder API
+# --------------------------------------------------------------------------
+def demo_fbs_exec_env():
+    # the reference's own __main__ demo, fbs_exec_env.py:279-301
+    env = LutExecEnv()
+    a = env.input("a"); b = env.input("b"); c = env.const(1)
+    d = env.linear([1, 2], [a, b])
+    e = env.linear([1, 1], [c, d])
+    f = env.bootstrap(e, [1, 0, 1, 1, 0])
+    g = env.linear([2, 1], [a, f])
+    h = env.bootstrap(g, [1, 1, 0, 2])
+    env.bootstrap(h, [1, 0, 1])
+    env.output("f", f); env.output("g", g); env.output("h", h)
+    vals = {"a": [1, 0], "b": [1, 0], "c": [1, 0]}
+    dump_case("demo_fbs_exec_env", env, vals, None, dict(circuit="demo", mapper="hand"))
+
+
+def demo_map_to_fbs():
+    # map_to_fbs.py:550-596 demo: same circuit through Basic / naive / search
+    def build():
+        env = BitExecEnv()
+        a = env.input("a"); b = env.input("b"); c = env.input("c")
+        d = env.op_lut([a, b], [0, 0, 0, 1])
+        e = env.op_lut([c, d], [0, 1, 1, 0])
+        f = env.op_lut([e, d], [0, 1, 0, 0])
+        env.output("d", d); env.output("e", e); env.output("f", f)
+        return env
+    vals = {"a": [0, 0, 1, 1], "b": [0, 1, 0, 1], "c": [0, 0, 1, 1]}
+    for mapper in ("basic", "naive", "search"):
+        bit_env = build()
+        out_bit = bit_env.eval(vals)
+        lut_env = make_mapper(mapper, 8, False).map(bit_env)
+        dump_case(f"demo_map_to_fbs__{mapper}", lut_env, vals, out_bit,
+                  dict(circuit="demo3", mapper=mapper, fbs_size=8, strict=False, max_fbs_size=16))
+
+
+def edge_programs():
+    # outputs that are an input / a constant / a NOT lincomb; CSE gaps in ids;
+    # nested lincombs with merging off; multi-valued tables
+    env = LutExecEnv()
+    a = env.input("a"); b = env.input("b")
+    na = env.linear([-1], [a], const_coef=1)
+    s = env.linear([1, 1], [a, b])
+    x1 = env.bootstrap(s, [0, 1, 0])
+    x2 = env.bootstrap(s, [0, 1, 0])        # CSE hit: id consumed, no new instr
+    c1 = env.bootstrap(s, [0, 0, 1])
+    t = env.linear([1, 2, 1], [x1, c1, env.const(1)])
+    y = env.bootstrap(t, [0, 1, 2, 3, 2])
+    env.output("pa", a)
+    env.output("z", env.const(0))
+    env.output("one", env.const(1))
+    env.output("na", na)
+    env.output("x", x2)
+    env.output("y", y)
+    vals = harness_inputs(["a", "b"], 64)
+    dump_case("edge_outputs", env, vals, None, dict(circuit="edge", mapper="hand"))
+
+    env = LutExecEnv(merge_linear_prods=False)
+    a = env.input("a"); b = env.input("b"); c = env.input("c")
+    l1 = env.linear([1, 1], [a, b])
+    l2 = env.linear([2, 1], [l1, c], const_coef=1)      # lincomb of a lincomb
+    z = env.bootstrap(l2, [0, 1, 1, 0, 1, 0, 1])
+    env.output("z", z)
+    env.output("l2", l2)
+    vals = harness_inputs(["a", "b", "c"], 64)
+    dump_case("edge_nomerge", env, vals, None, dict(circuit="edge", mapper="hand"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true",
+                    help="also map the full 1152-step trivium_stream_v2 (~30 min)")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    logging.disable(logging.CRITICAL)       # "Cone with sparse mvt" spam, map_to_fbs.py:202
+
+    def want(n):
+        return args.only is None or args.only in n
+
+    if want("demo"):
+        demo_fbs_exec_env()
+        demo_map_to_fbs()
+    if want("edge"):
+        edge_programs()
+    for case, fn in SMALL_GENERATORS.items():
+        if not want(case):
+            continue
+        for p in (2, 3, 7, 15, 31):
+            for mapper in ("basic", "naive", "search"):
+                if mapper == "basic" and p != 2:
+                    continue                 # Basic ignores fbs_size
+                map_and_dump(case, gen_from_reference(fn), mapper, p)
+            map_and_dump(case, gen_from_reference(fn), "search", p, strict=True)
+    if want("adder128"):
+        map_and_dump("adder128", ripple_adder(128), "search", 15)
+        map_and_dump("adder128", ripple_adder(128), "search", 31)
+    if want("adder8"):
+        map_and_dump("adder8", ripple_adder(8), "search", 15)
+        map_and_dump("adder8", ripple_adder(8), "search", 7)
+        map_and_dump("adder8", ripple_adder(8), "basic", 2)
+    if want("mul4"):
+        map_and_dump("mul4", array_multiplier(4), "search", 15)
+        map_and_dump("mul4", array_multiplier(4), "naive", 7)
+    if want("mul16"):
+        map_and_dump("mul16", array_multiplier(16), "search", 15)
+    if want("trivium_stream_short"):
+        map_and_dump("trivium_stream_short128", trivium_stream_short(128), "search", 15)
+    if args.big and want("trivium_stream_v2"):
+        map_and_dump("trivium_stream_v2", gen_from_reference(gb.TriviumStream.trivium_stream_v2),
+                     "search", 15)
+
+
+if __name__ == "__main__":
+    main()
