@@ -1,0 +1,159 @@
+/*
+ * fbs_exec.h -- C ABI of libfbsexec.so, the MI355X (gfx950) executor for the
+ * "linear combination + functional bootstrap" programs of ssmiler/tfhe_fbs_map.
+ *
+ * The reference has NO native/FFI boundary: its executor is the Python method
+ * `LutExecEnv.eval` (fbs_mapper/fbs_exec_env.py:208-229) and the only call
+ * site is fbs_mapper/map_circuit.py:174.  This header is therefore the
+ * boundary a maintainer would bind with ctypes from that method (stub in
+ * INTEGRATION.md).  Each entry point names the reference construct it stands
+ * behind.
+ *
+ * Conventions: every function returns 0 on success and a negative FBS_E_* code
+ * on failure (never throws, never aborts); `fbs_last_error` gives the text.
+ * Host buffers are caller-allocated, C-contiguous, 64-bit words unless stated;
+ * the library owns device memory and keys behind opaque handles.  A context is
+ * bound to one GPU and must be driven by one host thread at a time.  There is
+ * no CPU fallback: without a usable gfx950 device `fbs_ctx_create` fails.
+ *
+ * Ciphertexts are LWE samples over Z_q, q = 2^64 - 2^32 + 1, under the "big"
+ * key of dimension D = k*N: D mask words then the body, all canonical (< q).
+ * A message m in [0, 2p) is encoded as m * Delta, Delta = 2*round(q/4p), with
+ * p = `p_msg` the reference's `fbs_size` (map_circuit.py:97,117-122).
+ */
+#ifndef FBS_EXEC_H
+#define FBS_EXEC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBS_OK 0
+#define FBS_E_INVALID (-1)   /* bad argument / unsupported parameter set          */
+#define FBS_E_DEVICE (-2)    /* HIP error (no GPU, OOM, launch failure ...)       */
+#define FBS_E_STATE (-3)     /* call out of order (e.g. eval before keygen)       */
+#define FBS_E_TABLE (-4)     /* table violates the negacyclic contract for p      */
+
+typedef struct fbs_params {
+    uint32_t n;          /* small LWE dimension (P1024: 630)                      */
+    uint32_t log_n_poly; /* log2 of the GLWE polynomial size N (P1024: 10)        */
+    uint32_t k;          /* GLWE dimension; this build supports k = 1             */
+    uint32_t l_bsk;      /* blind-rotation gadget levels (3)                      */
+    uint32_t beta_bsk;   /* log2 blind-rotation gadget base (7)                   */
+    uint32_t t_ksk;      /* key-switch levels (8)                                 */
+    uint32_t gamma_ksk;  /* log2 key-switch base (2)                              */
+    uint32_t p_msg;      /* plaintext modulus p = fbs_size                        */
+    uint64_t sigma_lwe;  /* std-dev of key-switch-key noise, absolute (x q/2^64)  */
+    uint64_t sigma_glwe; /* std-dev of bootstrap-key and fresh-input noise        */
+} fbs_params;
+
+typedef struct fbs_ctx fbs_ctx;
+typedef struct fbs_tvset fbs_tvset;
+typedef struct fbs_prog fbs_prog;
+
+/* ---- context ------------------------------------------------------------ */
+/* device: HIP ordinal.  seed: all key material and encryption randomness is
+ * derived from it (ChaCha20 streams, DESIGN.md "Randomness"). */
+int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out);
+void fbs_ctx_destroy(fbs_ctx *ctx);
+/* text of the last failure on `ctx` (or of the last failed fbs_ctx_create when ctx == NULL) */
+const char *fbs_last_error(const fbs_ctx *ctx);
+/* "gfx950 <device name> CUs=<n>" of the bound device */
+const char *fbs_device_info(const fbs_ctx *ctx);
+
+/* ---- keys ----------------------------------------------------------------
+ * Secret keys stay on the host; the bootstrapping key (n GGSW samples) is
+ * uploaded, transformed to the NTT domain on the GPU and kept resident, as is
+ * the key-switching key. */
+int fbs_keygen(fbs_ctx *ctx);
+/* word counts of { sk_lwe, sk_glwe, bsk, ksk } in the standard (coefficient)
+ * layout  bsk[n][(k+1)l][k+1][N],  ksk[kN][t][n+1] */
+int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]);
+/* test hook: copy keys out (any pointer may be NULL) so a checker can be keyed identically */
+int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk);
+
+/* ---- encrypt / decrypt (host side, big key) ------------------------------
+ * Stand behind the Input arm of eval (fbs_exec_env.py:213-214) and the final
+ * read-out (:225-229).  Ciphertext i draws its randomness from stream
+ * nonce0 + i, so a run is reproducible. cts: [count][D+1]. */
+int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts);
+/* msgs[i] = round(phase * 2p / q) mod 2p */
+int fbs_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);
+
+/* ---- tables -> test vectors ----------------------------------------------
+ * One entry per distinct `Bootstrap.table` (fbs_exec_env.py:51-61).  Table t is
+ * table_vals[table_off[t] .. table_off[t+1]); length <= 2p, and where it
+ * exceeds p it must satisfy table[i] + table[i+p] == const (the three modes of
+ * map_to_fbs.py:81-98), else FBS_E_TABLE. */
+int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *table_off, uint32_t n_tables,
+                     fbs_tvset **out);
+void fbs_tvset_destroy(fbs_tvset *tv);
+
+/* ---- batch of independent functional bootstraps (BASELINE config 2) -------
+ * One FBS = key switch (kN -> n), modulus switch (q -> 2N), blind rotation
+ * (n CMUX), sample extraction: the encrypted form of `table[v]`
+ * (fbs_exec_env.py:218-220).  Host buffers: cts_in/out [count][D+1]. */
+int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_in, const uint32_t *table_ids,
+                        size_t count, uint64_t *cts_out);
+/* same on device-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the
+ * context's own stream).  d_table_ids is a device array of `count` uint32. */
+int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_cts_in,
+                            const uint32_t *d_table_ids, size_t count, uint64_t *d_cts_out, void *stream);
+
+/* ---- linear combination (LinearProd, fbs_exec_env.py:37-49, :215-217) ------
+ * out[g][s] = sum_i coefs[off[g]+i] * wires[srcs[off[g]+i]][s] + consts[g]*Delta  for g < n_out,
+ * s < T.  `d_wires` is a device array laid out [wire][T][D+1]; outputs are written to wire
+ * slots dst[g] of the same array.  term_off has n_out+1 entries.  Host index arrays. */
+int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *dst,
+                    const uint32_t *term_off, const uint32_t *srcs, const int64_t *coefs, const int64_t *consts,
+                    void *stream);
+/* bootstraps over wire slots: wire dst[g] = FBS(wire src[g], table table_ids[g]) for samples
+ * [s_begin, s_end) of each gate (the slice a rank owns in gate-sharded multi-GPU mode). */
+int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires, size_t T, uint32_t n_gates,
+                            const uint32_t *src, const uint32_t *dst, const uint32_t *table_ids, size_t s_begin,
+                            size_t s_end, void *stream);
+
+/* ---- whole program (LutExecEnv.eval, fbs_exec_env.py:208-229) ---------------
+ * Flat description of `LutExecEnv.instructions` after the Input entries:
+ *   wire ids: 0..n_inputs-1 are the inputs in program order, n_inputs+i is
+ *   instruction i.  kind[i]: 0 = LinearProd, 1 = Bootstrap.
+ *   LinearProd i: terms [arg0[i], arg0[i]+arg1[i]) of (term_coef, term_src), constant const_coef[i].
+ *   Bootstrap  i: source wire arg0[i], table id arg1[i] (into the fbs_tvset).
+ *   outputs: out_wire[o] >= 0 is a wire id; a constant output c is encoded as -1-c. */
+typedef struct fbs_program_desc {
+    uint32_t n_inputs, n_instr, n_terms, n_outputs;
+    const uint8_t *kind;
+    const uint32_t *arg0, *arg1;
+    const int64_t *const_coef;
+    const int64_t *term_coef;
+    const uint32_t *term_src;
+    const int64_t *out_wire;
+} fbs_program_desc;
+
+int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset *tv, fbs_prog **out);
+void fbs_program_destroy(fbs_prog *prog);
+/* depth (number of bootstrap levels) and the widest level, as scheduled */
+int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap);
+/* in_cts: host [n_inputs][T][D+1]; out_cts: host [n_outputs][T][D+1] (constant outputs are
+ * written as trivial ciphertexts).  Levels are batched over (gate, sample). */
+int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts);
+
+/* ---- measurement hooks ------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by HIP events on its own
+ * stream; fbs_profile_read synchronises and returns per-kernel totals since the
+ * last reset: ms[0]=keyswitch+modswitch, ms[1]=blind-rotate+extract, ms[2]=lincomb;
+ * launches[i] = number of launches. */
+int fbs_profile_enable(fbs_ctx *ctx, int on);
+int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+/* block until all work queued on the context's stream (or `stream`) has finished */
+int fbs_sync(fbs_ctx *ctx, void *stream);
+
+/* ---- debug hook: negacyclic product of two polynomials on the device NTT ---- */
+int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBS_EXEC_H */

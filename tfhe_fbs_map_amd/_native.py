@@ -1,0 +1,286 @@
+"""ctypes binding of libfbsexec.so (C ABI: include/fbs_exec.h).
+
+There is deliberately no fallback: if the shared library is missing or cannot be
+loaded, importing this module raises, and if no gfx950 GPU is present
+`Context(...)` raises `FbsError` -- the product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfbsexec.so")
+
+GOLDILOCKS = 0xFFFFFFFF00000001
+
+
+class FbsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"libfbsexec error {code}: {text}")
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [(f, C.c_uint32) for f in
+                ("n", "log_n_poly", "k", "l_bsk", "beta_bsk", "t_ksk", "gamma_ksk", "p_msg")] + \
+               [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64)]
+
+
+class _ProgramDesc(C.Structure):
+    _fields_ = [("n_inputs", C.c_uint32), ("n_instr", C.c_uint32), ("n_terms", C.c_uint32),
+                ("n_outputs", C.c_uint32),
+                ("kind", C.c_void_p), ("arg0", C.c_void_p), ("arg1", C.c_void_p),
+                ("const_coef", C.c_void_p), ("term_coef", C.c_void_p), ("term_src", C.c_void_p),
+                ("out_wire", C.c_void_p)]
+
+
+@dataclass(frozen=True)
+class Params:
+    """Cryptographic parameter set.  P1024 is BASELINE.md's synthetic set."""
+    n: int = 630
+    log_n_poly: int = 10
+    k: int = 1
+    l_bsk: int = 3
+    beta_bsk: int = 7
+    t_ksk: int = 8
+    gamma_ksk: int = 2
+    p_msg: int = 15
+    sigma_lwe: int = 1 << 24      # 2^-40 relative: reduced noise, see DESIGN.md "Noise"
+    sigma_glwe: int = 1 << 24
+
+    @property
+    def N(self):
+        return 1 << self.log_n_poly
+
+    @property
+    def big_dim(self):
+        return self.k * self.N
+
+    @property
+    def ct_words(self):
+        return self.big_dim + 1
+
+    def replace(self, **kw):
+        d = asdict(self)
+        d.update(kw)
+        return Params(**d)
+
+    def to_c(self):
+        return _Params(**asdict(self))
+
+    def bytes_per_fbs(self):
+        """Algorithmic bytes one FBS must consume: every
+        bootstrapping-key row and key-switching-key row once, its input and
+        output ciphertext and its test vector."""
+        N, k, n = self.N, self.k, self.n
+        ggsw = (k + 1) * self.l_bsk * (k + 1) * N * 8
+        bsk = n * ggsw
+        ksk = k * N * self.t_ksk * (n + 1) * 8
+        return bsk + ksk + 2 * (k * N + 1) * 8 + N * 8
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  tfhe_fbs_map_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
+    sig = {
+        "fbs_ctx_create": (i32, [C.POINTER(_Params), u64, i32, C.POINTER(vp)]),
+        "fbs_ctx_destroy": (None, [vp]),
+        "fbs_last_error": (C.c_char_p, [vp]),
+        "fbs_device_info": (C.c_char_p, [vp]),
+        "fbs_keygen": (i32, [vp]),
+        "fbs_key_sizes": (i32, [vp, C.POINTER(sz * 4)]),
+        "fbs_export_keys": (i32, [vp, vp, vp, vp, vp]),
+        "fbs_encrypt": (i32, [vp, vp, sz, u64, vp]),
+        "fbs_decrypt": (i32, [vp, vp, sz, vp]),
+        "fbs_tvset_create": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
+        "fbs_tvset_destroy": (None, [vp]),
+        "fbs_bootstrap_batch": (i32, [vp, vp, vp, vp, sz, vp]),
+        "fbs_bootstrap_batch_dev": (i32, [vp, vp, vp, vp, sz, vp, vp]),
+        "fbs_lincomb_dev": (i32, [vp, vp, sz, u32, vp, vp, vp, vp, vp, vp]),
+        "fbs_bootstrap_wires_dev": (i32, [vp, vp, vp, sz, u32, vp, vp, vp, sz, sz, vp]),
+        "fbs_program_load": (i32, [vp, C.POINTER(_ProgramDesc), vp, C.POINTER(vp)]),
+        "fbs_program_destroy": (None, [vp]),
+        "fbs_program_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+        "fbs_eval": (i32, [vp, vp, vp, sz, vp]),
+        "fbs_profile_enable": (i32, [vp, i32]),
+        "fbs_profile_read": (i32, [vp, C.POINTER(C.c_double * 3), C.POINTER(u64 * 3), i32]),
+        "fbs_sync": (i32, [vp, vp]),
+        "fbs_debug_polymul": (i32, [vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the library does not match the header
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
+    "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
+    "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
+    "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_destroy", "fbs_program_info",
+    "fbs_eval", "fbs_profile_enable", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
+)
+
+lib = _load()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class TvSet:
+    def __init__(self, ctx, tables):
+        self.ctx = ctx
+        self.tables = [list(map(int, t)) for t in tables]
+        vals = _c([v for t in self.tables for v in t] or [0], np.int32)
+        off = np.zeros(len(self.tables) + 1, np.uint32)
+        off[1:] = np.cumsum([len(t) for t in self.tables])
+        h = C.c_void_p()
+        ctx._check(lib.fbs_tvset_create(ctx._h, _ptr(vals), _ptr(off), len(self.tables), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.fbs_tvset_destroy(self._h)
+            self._h = None
+
+
+class Program:
+    def __init__(self, ctx, tvset, n_inputs, kind, arg0, arg1, const_coef, term_coef, term_src, out_wire):
+        self.ctx, self.tvset = ctx, tvset
+        self._keep = [_c(kind, np.uint8), _c(arg0, np.uint32), _c(arg1, np.uint32), _c(const_coef, np.int64),
+                      _c(term_coef, np.int64), _c(term_src, np.uint32), _c(out_wire, np.int64)]
+        k = self._keep
+        desc = _ProgramDesc(n_inputs, len(k[0]), len(k[4]), len(k[6]), *[_ptr(a) for a in k])
+        h = C.c_void_p()
+        ctx._check(lib.fbs_program_load(ctx._h, C.byref(desc), tvset._h, C.byref(h)))
+        self._h = h
+        self.n_inputs, self.n_outputs = n_inputs, len(k[6])
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.fbs_program_info(h, C.byref(a), C.byref(b), C.byref(c))
+        self.depth, self.max_width, self.n_bootstrap = a.value, b.value, c.value
+
+    def eval(self, in_cts, T):
+        ctw = self.ctx.params.ct_words
+        in_cts = _c(in_cts, np.uint64).reshape(self.n_inputs, T, ctw)
+        out = np.empty((self.n_outputs, T, ctw), np.uint64)
+        self.ctx._check(lib.fbs_eval(self.ctx._h, self._h, _ptr(in_cts), T, _ptr(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self.ctx._h:
+            lib.fbs_program_destroy(self._h)
+            self._h = None
+
+
+class Context:
+    """One GPU, one parameter set, one key set."""
+
+    def __init__(self, params: Params = Params(), seed: int = 1, device: int = 0, keygen: bool = True):
+        self.params = params
+        self.seed = seed
+        self._h = C.c_void_p()
+        cp = params.to_c()
+        rc = lib.fbs_ctx_create(C.byref(cp), seed, device, C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise FbsError(rc, lib.fbs_last_error(None).decode())
+        if keygen:
+            self.keygen()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FbsError(rc, lib.fbs_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib.fbs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def device_info(self):
+        return lib.fbs_device_info(self._h).decode()
+
+    def keygen(self):
+        self._check(lib.fbs_keygen(self._h))
+
+    def export_keys(self):
+        sizes = (C.c_size_t * 4)()
+        self._check(lib.fbs_key_sizes(self._h, C.byref(sizes)))
+        arrs = [np.empty(sizes[i], np.uint64) for i in range(4)]
+        self._check(lib.fbs_export_keys(self._h, *[_ptr(a) for a in arrs]))
+        return dict(sk_lwe=arrs[0], sk_glwe=arrs[1], bsk=arrs[2], ksk=arrs[3])
+
+    def encrypt(self, msgs, nonce0=0):
+        msgs = _c(msgs, np.int64)
+        cts = np.empty(msgs.shape + (self.params.ct_words,), np.uint64)
+        self._check(lib.fbs_encrypt(self._h, _ptr(msgs), msgs.size, nonce0, _ptr(cts)))
+        return cts
+
+    def decrypt(self, cts):
+        cts = _c(cts, np.uint64)
+        out = np.empty(cts.shape[:-1], np.int64)
+        self._check(lib.fbs_decrypt(self._h, _ptr(cts), out.size, _ptr(out)))
+        return out
+
+    def tvset(self, tables):
+        return TvSet(self, tables)
+
+    def bootstrap_batch(self, tvset, cts, table_ids=None):
+        cts = _c(cts, np.uint64)
+        count = cts.size // self.params.ct_words
+        ids = None if table_ids is None else _c(table_ids, np.uint32)
+        out = np.empty_like(cts)
+        self._check(lib.fbs_bootstrap_batch(self._h, tvset._h, _ptr(cts), _ptr(ids), count, _ptr(out)))
+        return out
+
+    # device-pointer entry points (ints from torch.Tensor.data_ptr()); asynchronous on `stream`
+    def bootstrap_batch_dev(self, tvset, d_in, d_table_ids, count, d_out, stream=0):
+        self._check(lib.fbs_bootstrap_batch_dev(self._h, tvset._h, d_in, d_table_ids or None, count, d_out,
+                                                stream or None))
+
+    def lincomb_dev(self, d_wires, T, dst, term_off, srcs, coefs, consts, stream=0):
+        dst, term_off, srcs = _c(dst, np.uint32), _c(term_off, np.uint32), _c(srcs, np.uint32)
+        coefs, consts = _c(coefs, np.int64), _c(consts, np.int64)
+        self._check(lib.fbs_lincomb_dev(self._h, d_wires, T, len(dst), _ptr(dst), _ptr(term_off), _ptr(srcs),
+                                        _ptr(coefs), _ptr(consts), stream or None))
+
+    def bootstrap_wires_dev(self, tvset, d_wires, T, src, dst, table_ids, s_begin, s_end, stream=0):
+        src, dst, table_ids = _c(src, np.uint32), _c(dst, np.uint32), _c(table_ids, np.uint32)
+        self._check(lib.fbs_bootstrap_wires_dev(self._h, tvset._h, d_wires, T, len(src), _ptr(src), _ptr(dst),
+                                                _ptr(table_ids), s_begin, s_end, stream or None))
+
+    def profile(self, on=True):
+        self._check(lib.fbs_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * 3)()
+        cnt = (C.c_uint64 * 3)()
+        self._check(lib.fbs_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)))
+        names = ("keyswitch", "blind_rotate", "lincomb")
+        return {n: dict(ms=ms[i], launches=int(cnt[i])) for i, n in enumerate(names)}
+
+    def sync(self, stream=0):
+        self._check(lib.fbs_sync(self._h, stream or None))
+
+    def debug_polymul(self, a, b):
+        a, b = _c(a, np.uint64), _c(b, np.uint64)
+        c = np.empty_like(a)
+        self._check(lib.fbs_debug_polymul(self._h, _ptr(a), _ptr(b), _ptr(c)))
+        return c

@@ -1,0 +1,643 @@
+// extern "C" surface of libfbsexec.so (declared in include/fbs_exec.h) and the level-scheduled
+// program executor that stands behind `LutExecEnv.eval` (reference fbs_mapper/fbs_exec_env.py:208-229).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+
+#include "fbs_internal.hpp"
+
+using namespace fbs;
+
+static thread_local std::string g_create_error;
+
+namespace fbs {
+int set_error(const fbs_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+}  // namespace fbs
+
+// ---------------------------------------------------------------------------------------------
+// program representation
+// ---------------------------------------------------------------------------------------------
+struct LincombStage {
+    uint32_t n_out = 0;
+    uint32_t *d_dst = nullptr, *d_term_off = nullptr, *d_srcs = nullptr;
+    uint64_t *d_coefs = nullptr, *d_consts = nullptr;
+};
+struct BootStage {
+    uint32_t n_gates = 0;
+    uint32_t *d_src = nullptr, *d_dst = nullptr, *d_table = nullptr;
+};
+struct fbs_prog {
+    fbs_ctx *ctx = nullptr;
+    const fbs_tvset *tv = nullptr;
+    uint32_t n_inputs = 0, n_instr = 0, n_outputs = 0, n_wires = 0;
+    uint32_t depth = 0, max_width = 0, n_bootstrap = 0;
+    std::vector<int64_t> out_wire;
+    // schedule: for level L = 0..depth: lincomb stages (dependency order), then the bootstraps of level L+1
+    std::vector<std::vector<LincombStage>> lin;   // [depth+1][sub]
+    std::vector<BootStage> boot;                  // [depth]  (boot[L] = bootstraps of level L+1)
+    std::vector<void *> allocations;
+    uint64_t *d_wires = nullptr;
+    size_t wires_T = 0;
+};
+
+template <typename T>
+static int to_device(fbs_ctx *ctx, fbs_prog *prog, const std::vector<T> &v, T **out) {
+    *out = nullptr;
+    if (v.empty()) return FBS_OK;
+    void *d = nullptr;
+    FBS_HIP(ctx, hipMalloc(&d, v.size() * sizeof(T)));
+    prog->allocations.push_back(d);
+    FBS_HIP(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T *)d;
+    return FBS_OK;
+}
+
+static hipStream_t pick(fbs_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+static int ensure_ms(fbs_ctx *ctx, size_t count) {
+    if (count <= ctx->ms_capacity) return FBS_OK;
+    if (ctx->d_ms) (void)hipFree(ctx->d_ms);
+    ctx->d_ms = nullptr;
+    ctx->ms_capacity = 0;
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ms, count * (ctx->p.n + 1) * sizeof(uint32_t)));
+    ctx->ms_capacity = count;
+    return FBS_OK;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) {
+    if (!params || !out) return set_error(nullptr, FBS_E_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<fbs_ctx> ctx(new fbs_ctx);
+    ctx->p = *params;
+    ctx->seed = seed;
+    ctx->device = device;
+    const fbs_params &p = ctx->p;
+    if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
+        p.t_ksk > 64)
+        return set_error(nullptr, FBS_E_INVALID, "parameter out of range");
+    ctx->N = 1u << p.log_n_poly;
+    ctx->D = p.k * ctx->N;
+    ctx->rows = (p.k + 1) * p.l_bsk;
+    ctx->ksk_stride = ((p.n + 1 + 255) / 256) * 256;
+    int rc = dev_supported(ctx.get());
+    if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
+    ctx->delta_half = (uint64_t)(((unsigned __int128)GQ + 2ull * p.p_msg) / (4ull * p.p_msg));
+    auto round_div = [](uint32_t e) {
+        unsigned __int128 d = (unsigned __int128)1 << e;
+        return (uint64_t)(((unsigned __int128)GQ + d / 2) / d);
+    };
+    for (uint32_t lv = 0; lv < p.l_bsk; lv++) ctx->g[lv] = round_div(p.beta_bsk * (lv + 1));
+    for (uint32_t v = 0; v < p.t_ksk; v++) ctx->h[v] = round_div(p.gamma_ksk * (v + 1));
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return set_error(nullptr, FBS_E_DEVICE, "no HIP device: libfbsexec has no CPU path (" + std::string(hipGetErrorString(e)) + ")");
+    if (device < 0 || device >= n_dev) return set_error(nullptr, FBS_E_INVALID, "device ordinal out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return set_error(nullptr, FBS_E_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return set_error(nullptr, FBS_E_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return set_error(nullptr, FBS_E_DEVICE, std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 code only");
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->devinfo = std::string(prop.gcnArchName) + " " + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return set_error(nullptr, FBS_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    *out = ctx.release();
+    return FBS_OK;
+}
+
+void fbs_ctx_destroy(fbs_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_ksk, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
+                    (void *)ctx->d_idx})
+        if (p) (void)hipFree(p);
+    for (auto &v : ctx->prof.pending)
+        for (auto &pr : v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    for (auto &pr : ctx->prof.pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *fbs_last_error(const fbs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *fbs_device_info(const fbs_ctx *ctx) { return ctx ? ctx->devinfo.c_str() : ""; }
+
+// ---------------------------------------------------------------------------------------------
+int fbs_keygen(fbs_ctx *ctx) {
+    if (!ctx) return FBS_E_INVALID;
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    host_keygen(ctx);
+    int rc = dev_upload_keys(ctx);
+    if (rc != FBS_OK) return rc;
+    ctx->have_keys = true;
+    return FBS_OK;
+}
+
+int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]) {
+    if (!ctx || !sizes) return FBS_E_INVALID;
+    sizes[0] = ctx->p.n;
+    sizes[1] = ctx->D;
+    sizes[2] = (size_t)ctx->p.n * ctx->rows * (ctx->p.k + 1) * ctx->N;
+    sizes[3] = (size_t)ctx->D * ctx->p.t_ksk * (ctx->p.n + 1);
+    return FBS_OK;
+}
+
+int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk) {
+    if (!ctx) return FBS_E_INVALID;
+    if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    if (sk_lwe) std::memcpy(sk_lwe, ctx->sk_lwe.data(), ctx->sk_lwe.size() * 8);
+    if (sk_glwe) std::memcpy(sk_glwe, ctx->sk_glwe.data(), ctx->sk_glwe.size() * 8);
+    if (bsk) std::memcpy(bsk, ctx->bsk.data(), ctx->bsk.size() * 8);
+    if (ksk) std::memcpy(ksk, ctx->ksk.data(), ctx->ksk.size() * 8);
+    return FBS_OK;
+}
+
+int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts) {
+    if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
+    if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    host_encrypt(ctx, msgs, count, nonce0, cts);
+    return FBS_OK;
+}
+
+int fbs_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs) {
+    if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
+    if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    host_decrypt(ctx, cts, count, msgs);
+    return FBS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *table_off, uint32_t n_tables, fbs_tvset **out) {
+    if (!ctx || !out || (n_tables && (!table_vals || !table_off))) return FBS_E_INVALID;
+    *out = nullptr;
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<fbs_tvset> tv(new fbs_tvset);
+    tv->ctx = ctx;
+    tv->n_tables = n_tables;
+    const uint32_t N = ctx->N;
+    std::vector<uint64_t> host((size_t)std::max(1u, n_tables) * N, 0);
+    tv->post.assign(std::max(1u, n_tables), 0);
+    for (uint32_t t = 0; t < n_tables; t++) {
+        if (table_off[t + 1] < table_off[t]) return set_error(ctx, FBS_E_INVALID, "table offsets must be non-decreasing");
+        int rc = host_build_tv(ctx, table_vals + table_off[t], table_off[t + 1] - table_off[t], host.data() + (size_t)t * N,
+                               &tv->post[t]);
+        if (rc != FBS_OK)
+            return set_error(ctx, rc, "table " + std::to_string(t) + " of length " + std::to_string(table_off[t + 1] - table_off[t]) +
+                                          " is not evaluable by one bootstrap at p = " + std::to_string(ctx->p.p_msg));
+    }
+    FBS_HIP(ctx, hipMalloc(&tv->d_tvs, host.size() * 8));
+    FBS_HIP(ctx, hipMalloc(&tv->d_post, tv->post.size() * 8));
+    FBS_HIP(ctx, hipMemcpy(tv->d_tvs, host.data(), host.size() * 8, hipMemcpyHostToDevice));
+    FBS_HIP(ctx, hipMemcpy(tv->d_post, tv->post.data(), tv->post.size() * 8, hipMemcpyHostToDevice));
+    *out = tv.release();
+    return FBS_OK;
+}
+
+void fbs_tvset_destroy(fbs_tvset *tv) {
+    if (!tv) return;
+    if (tv->ctx) (void)hipSetDevice(tv->ctx->device);
+    if (tv->d_tvs) (void)hipFree(tv->d_tvs);
+    if (tv->d_post) (void)hipFree(tv->d_post);
+    delete tv;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_ready(fbs_ctx *ctx, const fbs_tvset *tv) {
+    if (!ctx) return FBS_E_INVALID;
+    if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    if (tv && tv->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "test-vector set belongs to another context");
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    return FBS_OK;
+}
+
+int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_cts_in, const uint32_t *d_table_ids,
+                            size_t count, uint64_t *d_cts_out, void *stream) {
+    int rc = check_ready(ctx, tv);
+    if (rc != FBS_OK) return rc;
+    if (!tv || (count && (!d_cts_in || !d_cts_out))) return set_error(ctx, FBS_E_INVALID, "null argument");
+    if (count == 0) return FBS_OK;
+    if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large");
+    rc = ensure_ms(ctx, count);
+    if (rc != FBS_OK) return rc;
+    GateView gv{};
+    gv.in_base = d_cts_in;
+    gv.out_base = d_cts_out;
+    gv.table_ids = d_table_ids;
+    gv.T = 1;
+    gv.s_begin = 0;
+    gv.s_count = 1;
+    gv.n_gates = (uint32_t)count;
+    hipStream_t s = pick(ctx, stream);
+    rc = dev_keyswitch(ctx, gv, ctx->d_ms, s);
+    if (rc != FBS_OK) return rc;
+    return dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+}
+
+int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_in, const uint32_t *table_ids, size_t count,
+                        uint64_t *cts_out) {
+    int rc = check_ready(ctx, tv);
+    if (rc != FBS_OK) return rc;
+    if (!tv || (count && (!cts_in || !cts_out))) return set_error(ctx, FBS_E_INVALID, "null argument");
+    if (count == 0) return FBS_OK;
+    if (table_ids)
+        for (size_t i = 0; i < count; i++)
+            if (table_ids[i] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
+    const size_t words = count * (ctx->D + 1);
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    uint32_t *d_tab = nullptr;
+    auto cleanup = [&] {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_tab) (void)hipFree(d_tab);
+    };
+#define TRY(call)                                                                                           \
+    do {                                                                                                    \
+        hipError_t e__ = (call);                                                                            \
+        if (e__ != hipSuccess) {                                                                            \
+            cleanup();                                                                                      \
+            return set_error(ctx, FBS_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__));        \
+        }                                                                                                   \
+    } while (0)
+    TRY(hipMalloc(&d_in, words * 8));
+    TRY(hipMalloc(&d_out, words * 8));
+    TRY(hipMemcpyAsync(d_in, cts_in, words * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (table_ids) {
+        TRY(hipMalloc(&d_tab, count * 4));
+        TRY(hipMemcpyAsync(d_tab, table_ids, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = fbs_bootstrap_batch_dev(ctx, tv, d_in, d_tab, count, d_out, nullptr);
+    if (rc != FBS_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        cleanup();
+        return rc;
+    }
+    TRY(hipMemcpyAsync(cts_out, d_out, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TRY(hipStreamSynchronize(ctx->stream));
+#undef TRY
+    cleanup();
+    return FBS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wire-slot building blocks (the multi-GPU host drives these level by level)
+// ---------------------------------------------------------------------------------------------
+static int ensure_idx(fbs_ctx *ctx, size_t words) {
+    if (words <= ctx->idx_capacity) return FBS_OK;
+    if (ctx->d_idx) {
+        FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_idx);
+    }
+    ctx->d_idx = nullptr;
+    ctx->idx_capacity = 0;
+    size_t cap = std::max<size_t>(words, 1 << 16);
+    FBS_HIP(ctx, hipMalloc(&ctx->d_idx, cap * 4));
+    ctx->idx_capacity = cap;
+    return FBS_OK;
+}
+
+int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *dst, const uint32_t *term_off,
+                    const uint32_t *srcs, const int64_t *coefs, const int64_t *consts, void *stream) {
+    int rc = check_ready(ctx, nullptr);
+    if (rc != FBS_OK) return rc;
+    if (n_out == 0 || T == 0) return FBS_OK;
+    if (!d_wires || !dst || !term_off || !consts) return set_error(ctx, FBS_E_INVALID, "null argument");
+    const uint32_t n_terms = term_off[n_out];
+    // staging: [dst n_out][term_off n_out+1][srcs n_terms] as u32, then coefs and consts as u64
+    size_t u32_words = (size_t)n_out + (n_out + 1) + n_terms;
+    u32_words = (u32_words + 1) & ~(size_t)1;
+    size_t total = u32_words + 2 * ((size_t)n_terms + n_out);
+    hipStream_t s = pick(ctx, stream);
+    FBS_HIP(ctx, hipStreamSynchronize(s));   // the staging buffer may still be read by the previous call
+    rc = ensure_idx(ctx, total);
+    if (rc != FBS_OK) return rc;
+    std::vector<uint32_t> stage(total, 0);
+    std::memcpy(stage.data(), dst, (size_t)n_out * 4);
+    std::memcpy(stage.data() + n_out, term_off, (size_t)(n_out + 1) * 4);
+    if (n_terms) std::memcpy(stage.data() + 2 * (size_t)n_out + 1, srcs, (size_t)n_terms * 4);
+    uint64_t *f = reinterpret_cast<uint64_t *>(stage.data() + u32_words);
+    for (uint32_t i = 0; i < n_terms; i++) f[i] = gl_from_i64(coefs[i]);
+    for (uint32_t g = 0; g < n_out; g++) f[n_terms + g] = gl_mul(gl_from_i64(consts[g]), 2 * ctx->delta_half);
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_idx, stage.data(), total * 4, hipMemcpyHostToDevice, s));
+    FBS_HIP(ctx, hipStreamSynchronize(s));   // `stage` is pageable host memory going out of scope
+    const uint32_t *d_dst = ctx->d_idx, *d_off = ctx->d_idx + n_out, *d_srcs = ctx->d_idx + 2 * (size_t)n_out + 1;
+    const uint64_t *d_f = reinterpret_cast<const uint64_t *>(ctx->d_idx + u32_words);
+    return dev_lincomb(ctx, d_wires, T, n_out, d_dst, d_off, d_srcs, d_f, d_f + n_terms, s);
+}
+
+int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires, size_t T, uint32_t n_gates,
+                            const uint32_t *src, const uint32_t *dst, const uint32_t *table_ids, size_t s_begin, size_t s_end,
+                            void *stream) {
+    int rc = check_ready(ctx, tv);
+    if (rc != FBS_OK) return rc;
+    if (!tv || !d_wires || !src || !dst || !table_ids) return set_error(ctx, FBS_E_INVALID, "null argument");
+    if (s_end > T || s_begin > s_end) return set_error(ctx, FBS_E_INVALID, "bad sample range");
+    if (n_gates == 0 || s_begin == s_end) return FBS_OK;
+    const size_t count = (size_t)n_gates * (s_end - s_begin);
+    hipStream_t s = pick(ctx, stream);
+    FBS_HIP(ctx, hipStreamSynchronize(s));
+    rc = ensure_idx(ctx, 3 * (size_t)n_gates);
+    if (rc != FBS_OK) return rc;
+    rc = ensure_ms(ctx, count);
+    if (rc != FBS_OK) return rc;
+    std::vector<uint32_t> stage(3 * (size_t)n_gates);
+    std::memcpy(stage.data(), src, (size_t)n_gates * 4);
+    std::memcpy(stage.data() + n_gates, dst, (size_t)n_gates * 4);
+    std::memcpy(stage.data() + 2 * (size_t)n_gates, table_ids, (size_t)n_gates * 4);
+    for (uint32_t g = 0; g < n_gates; g++)
+        if (table_ids[g] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_idx, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, s));
+    FBS_HIP(ctx, hipStreamSynchronize(s));
+    GateView gv{};
+    gv.in_base = d_wires;
+    gv.out_base = d_wires;
+    gv.src_slot = ctx->d_idx;
+    gv.dst_slot = ctx->d_idx + n_gates;
+    gv.table_ids = ctx->d_idx + 2 * (size_t)n_gates;
+    gv.T = T;
+    gv.s_begin = s_begin;
+    gv.s_count = s_end - s_begin;
+    gv.n_gates = n_gates;
+    rc = dev_keyswitch(ctx, gv, ctx->d_ms, s);
+    if (rc != FBS_OK) return rc;
+    return dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole-program executor
+// ---------------------------------------------------------------------------------------------
+int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, fbs_prog **out) {
+    int rc = check_ready(ctx, tv);
+    if (rc != FBS_OK) return rc;
+    if (!d || !out) return set_error(ctx, FBS_E_INVALID, "null argument");
+    *out = nullptr;
+    std::unique_ptr<fbs_prog, void (*)(fbs_prog *)> prog(new fbs_prog, fbs_program_destroy);
+    prog->ctx = ctx;
+    prog->tv = tv;
+    prog->n_inputs = d->n_inputs;
+    prog->n_instr = d->n_instr;
+    prog->n_outputs = d->n_outputs;
+    prog->n_wires = d->n_inputs + d->n_instr;
+    prog->out_wire.assign(d->out_wire, d->out_wire + d->n_outputs);
+
+    // levels: inputs 0, LinearProd = max over sources, Bootstrap = source + 1
+    std::vector<uint32_t> level(prog->n_wires, 0), sub(prog->n_wires, 0);
+    std::vector<uint8_t> is_lin(prog->n_wires, 0);
+    for (uint32_t i = 0; i < d->n_instr; i++) {
+        const uint32_t w = d->n_inputs + i;
+        if (d->kind[i] == 0) {
+            is_lin[w] = 1;
+            if ((uint64_t)d->arg0[i] + d->arg1[i] > d->n_terms) return set_error(ctx, FBS_E_INVALID, "term range out of bounds");
+            uint32_t lv = 0, sb = 0;
+            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
+                const uint32_t s = d->term_src[t];
+                if (s >= w) return set_error(ctx, FBS_E_INVALID, "instruction " + std::to_string(i) + " reads a later wire");
+                lv = std::max(lv, level[s]);
+            }
+            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
+                const uint32_t s = d->term_src[t];
+                if (is_lin[s] && level[s] == lv) sb = std::max(sb, sub[s] + 1);
+            }
+            level[w] = lv;
+            sub[w] = sb;
+        } else if (d->kind[i] == 1) {
+            if (d->arg0[i] >= w) return set_error(ctx, FBS_E_INVALID, "instruction " + std::to_string(i) + " reads a later wire");
+            if (!tv || d->arg1[i] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
+            level[w] = level[d->arg0[i]] + 1;
+            prog->depth = std::max(prog->depth, level[w]);
+            prog->n_bootstrap++;
+        } else {
+            return set_error(ctx, FBS_E_INVALID, "unknown instruction kind");
+        }
+    }
+    for (uint32_t o = 0; o < d->n_outputs; o++)
+        if (d->out_wire[o] >= (int64_t)prog->n_wires) return set_error(ctx, FBS_E_INVALID, "output wire out of range");
+
+    const uint32_t depth = prog->depth;
+    prog->lin.resize(depth + 1);
+    prog->boot.resize(depth);
+    struct LinHost {
+        std::vector<uint32_t> dst, off{0}, srcs;
+        std::vector<uint64_t> coefs, consts;
+    };
+    std::vector<std::vector<LinHost>> lh(depth + 1);
+    struct BootHost {
+        std::vector<uint32_t> src, dst, tab;
+    };
+    std::vector<BootHost> bh(depth);
+    for (uint32_t i = 0; i < d->n_instr; i++) {
+        const uint32_t w = d->n_inputs + i;
+        if (d->kind[i] == 0) {
+            auto &stages = lh[level[w]];
+            if (stages.size() <= sub[w]) stages.resize(sub[w] + 1);
+            LinHost &h = stages[sub[w]];
+            h.dst.push_back(w);
+            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
+                h.srcs.push_back(d->term_src[t]);
+                h.coefs.push_back(gl_from_i64(d->term_coef[t]));
+            }
+            h.off.push_back((uint32_t)h.srcs.size());
+            h.consts.push_back(gl_mul(gl_from_i64(d->const_coef[i]), 2 * ctx->delta_half));
+        } else {
+            BootHost &b = bh[level[w] - 1];
+            b.src.push_back(d->arg0[i]);
+            b.dst.push_back(w);
+            b.tab.push_back(d->arg1[i]);
+        }
+    }
+    for (uint32_t L = 0; L <= depth; L++) {
+        for (LinHost &h : lh[L]) {
+            if (h.dst.empty()) continue;
+            // k_lincomb's grid.y carries the output index: split very wide stages
+            for (size_t a = 0; a < h.dst.size(); a += 32768) {
+                size_t b = std::min(h.dst.size(), a + 32768);
+                LincombStage st;
+                st.n_out = (uint32_t)(b - a);
+                std::vector<uint32_t> dst(h.dst.begin() + a, h.dst.begin() + b), off;
+                const uint32_t t0 = h.off[a];
+                for (size_t g = a; g <= b; g++) off.push_back(h.off[g] - t0);
+                std::vector<uint32_t> srcs(h.srcs.begin() + t0, h.srcs.begin() + h.off[b]);
+                std::vector<uint64_t> coefs(h.coefs.begin() + t0, h.coefs.begin() + h.off[b]);
+                std::vector<uint64_t> consts(h.consts.begin() + a, h.consts.begin() + b);
+                if ((rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), off, &st.d_term_off)) ||
+                    (rc = to_device(ctx, prog.get(), srcs, &st.d_srcs)) || (rc = to_device(ctx, prog.get(), coefs, &st.d_coefs)) ||
+                    (rc = to_device(ctx, prog.get(), consts, &st.d_consts)))
+                    return rc;
+                prog->lin[L].push_back(st);
+            }
+        }
+    }
+    for (uint32_t L = 0; L < depth; L++) {
+        BootStage st;
+        st.n_gates = (uint32_t)bh[L].src.size();
+        prog->max_width = std::max(prog->max_width, st.n_gates);
+        if ((rc = to_device(ctx, prog.get(), bh[L].src, &st.d_src)) || (rc = to_device(ctx, prog.get(), bh[L].dst, &st.d_dst)) ||
+            (rc = to_device(ctx, prog.get(), bh[L].tab, &st.d_table)))
+            return rc;
+        prog->boot[L] = st;
+    }
+    *out = prog.release();
+    return FBS_OK;
+}
+
+void fbs_program_destroy(fbs_prog *prog) {
+    if (!prog) return;
+    if (prog->ctx) (void)hipSetDevice(prog->ctx->device);
+    for (void *p : prog->allocations) (void)hipFree(p);
+    if (prog->d_wires) (void)hipFree(prog->d_wires);
+    delete prog;
+}
+
+int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap) {
+    if (!prog) return FBS_E_INVALID;
+    if (n_levels) *n_levels = prog->depth;
+    if (max_width) *max_width = prog->max_width;
+    if (n_bootstrap) *n_bootstrap = prog->n_bootstrap;
+    return FBS_OK;
+}
+
+int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts) {
+    int rc = check_ready(ctx, prog ? prog->tv : nullptr);
+    if (rc != FBS_OK) return rc;
+    if (!prog || prog->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "program belongs to another context");
+    if (T == 0) return FBS_OK;
+    if ((prog->n_inputs && !in_cts) || (prog->n_outputs && !out_cts)) return set_error(ctx, FBS_E_INVALID, "null argument");
+    const size_t ctw = ctx->D + 1;
+    hipStream_t s = ctx->stream;
+
+    // samples are independent through the whole program: evaluate in chunks that fit in HBM
+    size_t free_b = 0, total_b = 0;
+    FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t per_sample = (size_t)prog->n_wires * ctw * 8 + (size_t)prog->max_width * (ctx->p.n + 1) * 4;
+    size_t have = free_b + prog->wires_T * (size_t)prog->n_wires * ctw * 8;
+    size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / std::max<size_t>(1, per_sample)));
+    if (prog->wires_T < Tc) {
+        if (prog->d_wires) (void)hipFree(prog->d_wires);
+        prog->d_wires = nullptr;
+        prog->wires_T = 0;
+        FBS_HIP(ctx, hipMalloc(&prog->d_wires, Tc * (size_t)prog->n_wires * ctw * 8));
+        prog->wires_T = Tc;
+    }
+    const size_t TW = prog->wires_T;   // sample stride of the wire buffer
+    rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_width) * std::min(Tc, T));
+    if (rc != FBS_OK) return rc;
+
+    for (size_t s0 = 0; s0 < T; s0 += Tc) {
+        const size_t tc = std::min(Tc, T - s0);
+        for (uint32_t i = 0; i < prog->n_inputs; i++)
+            FBS_HIP(ctx, hipMemcpyAsync(prog->d_wires + (size_t)i * TW * ctw, in_cts + ((size_t)i * T + s0) * ctw, tc * ctw * 8,
+                                        hipMemcpyHostToDevice, s));
+        for (uint32_t L = 0; L <= prog->depth; L++) {
+            for (const LincombStage &st : prog->lin[L]) {
+                // grid.x = samples actually present in this chunk; the buffer stride stays TW
+                rc = dev_lincomb(ctx, prog->d_wires, TW, st.n_out, st.d_dst, st.d_term_off, st.d_srcs, st.d_coefs, st.d_consts, s);
+                if (rc != FBS_OK) return rc;
+            }
+            if (L == prog->depth) break;
+            const BootStage &b = prog->boot[L];
+            GateView gv{};
+            gv.in_base = prog->d_wires;
+            gv.out_base = prog->d_wires;
+            gv.src_slot = b.d_src;
+            gv.dst_slot = b.d_dst;
+            gv.table_ids = b.d_table;
+            gv.T = TW;
+            gv.s_begin = 0;
+            gv.s_count = tc;
+            gv.n_gates = b.n_gates;
+            if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+            if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+        }
+        for (uint32_t o = 0; o < prog->n_outputs; o++) {
+            uint64_t *dst = out_cts + ((size_t)o * T + s0) * ctw;
+            const int64_t w = prog->out_wire[o];
+            if (w >= 0) {
+                FBS_HIP(ctx, hipMemcpyAsync(dst, prog->d_wires + (size_t)w * TW * ctw, tc * ctw * 8, hipMemcpyDeviceToHost, s));
+            } else {
+                const uint64_t body = gl_mul(gl_from_i64(-1 - w), 2 * ctx->delta_half);   // trivial ciphertext of the constant
+                for (size_t q = 0; q < tc; q++) {
+                    std::memset(dst + q * ctw, 0, ctx->D * 8);
+                    dst[q * ctw + ctx->D] = body;
+                }
+            }
+        }
+        FBS_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return FBS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int fbs_profile_enable(fbs_ctx *ctx, int on) {
+    if (!ctx) return FBS_E_INVALID;
+    ctx->prof.on = on != 0;
+    return FBS_OK;
+}
+
+int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
+    if (!ctx) return FBS_E_INVALID;
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int k = 0; k < 3; k++) {
+        for (auto &pr : ctx->prof.pending[k]) {
+            FBS_HIP(ctx, hipEventSynchronize(pr.second));
+            float t = 0;
+            FBS_HIP(ctx, hipEventElapsedTime(&t, pr.first, pr.second));
+            ctx->prof.ms[k] += t;
+            ctx->prof.launches[k]++;
+            ctx->prof.pool.push_back(pr);
+        }
+        ctx->prof.pending[k].clear();
+        if (ms) ms[k] = ctx->prof.ms[k];
+        if (launches) launches[k] = ctx->prof.launches[k];
+        if (reset) {
+            ctx->prof.ms[k] = 0;
+            ctx->prof.launches[k] = 0;
+        }
+    }
+    return FBS_OK;
+}
+
+int fbs_sync(fbs_ctx *ctx, void *stream) {
+    if (!ctx) return FBS_E_INVALID;
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    FBS_HIP(ctx, hipStreamSynchronize(pick(ctx, stream)));
+    return FBS_OK;
+}
+
+int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c) {
+    int rc = check_ready(ctx, nullptr);
+    if (rc != FBS_OK) return rc;
+    const size_t bytes = (size_t)ctx->N * 8;
+    uint64_t *d = nullptr;
+    FBS_HIP(ctx, hipMalloc(&d, 3 * bytes));
+    hipError_t e = hipMemcpy(d, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + ctx->N, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = dev_polymul(ctx, d, d + ctx->N, d + 2 * (size_t)ctx->N, ctx->stream);
+        if (rc == FBS_OK) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess && rc == FBS_OK) e = hipMemcpy(c, d + 2 * (size_t)ctx->N, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (rc != FBS_OK) return rc;
+    if (e != hipSuccess) return set_error(ctx, FBS_E_DEVICE, std::string("polymul: ") + hipGetErrorString(e));
+    return FBS_OK;
+}
+
+}  // extern "C"

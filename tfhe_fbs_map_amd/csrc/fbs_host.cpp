@@ -1,0 +1,254 @@
+// Host side of libfbsexec.so: key generation, encryption/decryption and test-vector construction.
+// None of this is on the timed path; it exists so that the drop-in `LutExecEnv.eval`
+// (reference fbs_mapper/fbs_exec_env.py:208-229) can take cleartext bits in and hand cleartext
+// values back, as the reference's harness (fbs_mapper/map_circuit.py:137-180) expects.
+#include <algorithm>
+#include <functional>
+#include <cstring>
+#include <thread>
+
+#include "fbs_internal.hpp"
+
+namespace fbs {
+
+// ---------------------------------------------------------------------------------------------
+// ChaCha20, original 64-bit-counter layout.  key = seed || fixed tail, nonce = stream id.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ChaCha {
+    uint32_t in[16];
+    ChaCha(uint64_t seed, uint64_t stream) {
+        static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+        // key words 2..7 spell "fbs-exec-amd-gfx950-key1"
+        static const uint32_t tail[6] = {0x2d736266u, 0x63657865u, 0x646d612du, 0x7866672du, 0x2d303539u, 0x3179656bu};
+        for (int i = 0; i < 4; i++) in[i] = sigma[i];
+        in[4] = (uint32_t)seed;
+        in[5] = (uint32_t)(seed >> 32);
+        for (int i = 0; i < 6; i++) in[6 + i] = tail[i];
+        in[12] = in[13] = 0;
+        in[14] = (uint32_t)stream;
+        in[15] = (uint32_t)(stream >> 32);
+    }
+    static uint32_t rol(uint32_t v, int s) { return (v << s) | (v >> (32 - s)); }
+    static void quarter(uint32_t *x, int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rol(x[d] ^ x[a], 16);
+        x[c] += x[d]; x[b] = rol(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rol(x[d] ^ x[a], 8);
+        x[c] += x[d]; x[b] = rol(x[b] ^ x[c], 7);
+    }
+    void block(uint64_t counter, uint64_t out[8]) {
+        uint32_t x[16];
+        in[12] = (uint32_t)counter;
+        in[13] = (uint32_t)(counter >> 32);
+        std::memcpy(x, in, sizeof x);
+        for (int round = 0; round < 20; round += 2) {
+            quarter(x, 0, 4, 8, 12); quarter(x, 1, 5, 9, 13); quarter(x, 2, 6, 10, 14); quarter(x, 3, 7, 11, 15);
+            quarter(x, 0, 5, 10, 15); quarter(x, 1, 6, 11, 12); quarter(x, 2, 7, 8, 13); quarter(x, 3, 4, 9, 14);
+        }
+        for (int i = 0; i < 8; i++)
+            out[i] = (uint64_t)(x[2 * i] + in[2 * i]) | ((uint64_t)(x[2 * i + 1] + in[2 * i + 1]) << 32);
+    }
+};
+inline uint64_t fold(uint64_t r) { return r >= GQ ? r - GQ : r; }   // 2^-32 bias, documented
+}  // namespace
+
+void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count) {
+    ChaCha c(seed, stream);
+    uint64_t blk[8];
+    uint64_t have = ~0ull;
+    for (size_t i = 0; i < count; i++) {
+        uint64_t idx = idx0 + i;
+        if ((idx >> 3) != have) {
+            have = idx >> 3;
+            c.block(have, blk);
+        }
+        dst[i] = blk[idx & 7];
+    }
+}
+
+// Integer-only Gaussian stand-in (Irwin-Hall, 12 uniform 32-bit terms, variance 2^64), scaled by
+// sigma / 2^32 and rounded half-up.  Bounded at 6 sigma; fine for tests, not a production sampler.
+int64_t noise_sample(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t sigma) {
+    if (!sigma) return 0;
+    uint64_t w[6];
+    rand_words(seed, stream, idx * 6, w, 6);
+    __int128 s = -(__int128)6 * 0xFFFFFFFFll;
+    for (uint64_t v : w) s += (__int128)(uint32_t)v + (__int128)(v >> 32);
+    return (int64_t)((s * (__int128)sigma + ((__int128)1 << 31)) >> 32);
+}
+
+static void parallel_for(size_t n, const std::function<void(size_t, size_t)> &body) {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    size_t workers = std::min<size_t>(hw, std::max<size_t>(1, n));
+    if (workers <= 1) {
+        body(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    size_t chunk = (n + workers - 1) / workers;
+    for (size_t w = 0; w < workers; w++) {
+        size_t a = w * chunk, b = std::min(n, a + chunk);
+        if (a >= b) break;
+        pool.emplace_back([=, &body] { body(a, b); });
+    }
+    for (auto &t : pool) t.join();
+}
+
+// ---------------------------------------------------------------------------------------------
+// keys
+// ---------------------------------------------------------------------------------------------
+void host_keygen(fbs_ctx *ctx) {
+    const fbs_params &p = ctx->p;
+    const uint32_t N = ctx->N, D = ctx->D, n = p.n, k = p.k, l = p.l_bsk, t = p.t_ksk, rows = ctx->rows;
+    ctx->sk_lwe.assign(n, 0);
+    ctx->sk_glwe.assign(D, 0);
+    {
+        std::vector<uint64_t> w(std::max(n, D));
+        rand_words(ctx->seed, stream_id(DOM_SK_LWE, 0), 0, w.data(), n);
+        for (uint32_t i = 0; i < n; i++) ctx->sk_lwe[i] = w[i] & 1;
+        rand_words(ctx->seed, stream_id(DOM_SK_GLWE, 0), 0, w.data(), D);
+        for (uint32_t i = 0; i < D; i++) ctx->sk_glwe[i] = w[i] & 1;
+    }
+    // support of each GLWE key polynomial (binary key => A*S is a signed sum of shifted copies of A)
+    std::vector<std::vector<uint32_t>> support(k);
+    for (uint32_t c = 0; c < k; c++)
+        for (uint32_t i = 0; i < N; i++)
+            if (ctx->sk_glwe[(size_t)c * N + i]) support[c].push_back(i);
+
+    const size_t row_words = (size_t)(k + 1) * N;
+    ctx->bsk.assign((size_t)n * rows * row_words, 0);
+    parallel_for((size_t)n * rows, [&](size_t r0, size_t r1) {
+        std::vector<uint64_t> prod(N);
+        for (size_t r = r0; r < r1; r++) {
+            uint32_t i = (uint32_t)(r / rows), rr = (uint32_t)(r % rows), comp = rr / l, lv = rr % l;
+            uint64_t *row = ctx->bsk.data() + r * row_words;
+            uint64_t *body = row + (size_t)k * N;
+            for (uint32_t j = 0; j < N; j++)
+                body[j] = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_BSK_NOISE, r), j, p.sigma_glwe));
+            for (uint32_t c = 0; c < k; c++) {
+                uint64_t *a = row + (size_t)c * N;
+                rand_words(ctx->seed, stream_id(DOM_BSK_MASK, r), (uint64_t)c * N, a, N);
+                for (uint32_t j = 0; j < N; j++) a[j] = fold(a[j]);
+                std::fill(prod.begin(), prod.end(), 0);
+                for (uint32_t sh : support[c]) {
+                    // prod += X^sh * a
+                    for (uint32_t j = 0; j < N - sh; j++) prod[j + sh] = gl_add(prod[j + sh], a[j]);
+                    for (uint32_t j = N - sh; j < N; j++) prod[j + sh - N] = gl_sub(prod[j + sh - N], a[j]);
+                }
+                for (uint32_t j = 0; j < N; j++) body[j] = gl_add(body[j], prod[j]);
+            }
+            if (ctx->sk_lwe[i]) row[(size_t)comp * N] = gl_add(row[(size_t)comp * N], ctx->g[lv]);
+        }
+    });
+
+    ctx->ksk.assign((size_t)D * t * (n + 1), 0);
+    parallel_for((size_t)D * t, [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; r++) {
+            uint32_t j = (uint32_t)(r / t), v = (uint32_t)(r % t);
+            uint64_t *row = ctx->ksk.data() + r * (n + 1);
+            rand_words(ctx->seed, stream_id(DOM_KSK_MASK, r), 0, row, n);
+            uint64_t b = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_KSK_NOISE, r), 0, p.sigma_lwe));
+            for (uint32_t i = 0; i < n; i++) {
+                row[i] = fold(row[i]);
+                if (ctx->sk_lwe[i]) b = gl_add(b, row[i]);
+            }
+            if (ctx->sk_glwe[j]) b = gl_add(b, ctx->h[v]);
+            row[n] = b;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// encrypt / decrypt under the big key
+// ---------------------------------------------------------------------------------------------
+void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts) {
+    const uint32_t D = ctx->D;
+    const uint64_t delta = 2 * ctx->delta_half;
+    parallel_for(count, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            uint64_t *ct = cts + i * (D + 1);
+            rand_words(ctx->seed, stream_id(DOM_ENC_MASK, nonce0 + i), 0, ct, D);
+            uint64_t body = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_ENC_NOISE, nonce0 + i), 0, ctx->p.sigma_glwe));
+            for (uint32_t j = 0; j < D; j++) {
+                ct[j] = fold(ct[j]);
+                if (ctx->sk_glwe[j]) body = gl_add(body, ct[j]);
+            }
+            ct[D] = gl_add(body, gl_mul(gl_from_i64(msgs[i]), delta));
+        }
+    });
+}
+
+void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs) {
+    const uint32_t D = ctx->D;
+    const uint64_t two_p = 2ull * ctx->p.p_msg;
+    parallel_for(count, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const uint64_t *ct = cts + i * (D + 1);
+            uint64_t phase = ct[D];
+            for (uint32_t j = 0; j < D; j++)
+                if (ctx->sk_glwe[j]) phase = gl_sub(phase, ct[j]);
+            unsigned __int128 v = (unsigned __int128)phase * two_p + GQ / 2;
+            msgs[i] = (int64_t)((uint64_t)(v / GQ) % two_p);
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// test vector for one table.  A table longer than p is only computable when the values met at
+// x and x+p add up to one constant c (the reference's three "modes", map_to_fbs.py:81-98 are
+// c = 1, 0, 2): then f - c/2 is negacyclic, the polynomial carries (2f - c) * Delta/2 and c*Delta/2
+// is added back after sample extraction.
+// ---------------------------------------------------------------------------------------------
+int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64_t *tv, uint64_t *post_add) {
+    const uint32_t p = ctx->p.p_msg, N = ctx->N;
+    if (len == 0 || len > 2 * p) return FBS_E_TABLE;
+    int64_t c = 0;
+    if (len > p) {
+        c = (int64_t)table[0] + table[p];
+        for (uint32_t i = 0; i + p < len; i++)
+            if ((int64_t)table[i] + table[i + p] != c) return FBS_E_TABLE;
+    }
+    std::vector<uint64_t> enc(p);
+    for (uint32_t x = 0; x < p; x++) {
+        int64_t f = x < len ? table[x] : 0;   // unreachable slots
+        enc[x] = gl_mul(gl_from_i64(2 * f - c), ctx->delta_half);
+    }
+    for (uint32_t j = 0; j < N; j++) {
+        uint64_t x = ((uint64_t)j * 2 * p + N) / (2ull * N);   // nearest multiple of N/p
+        tv[j] = x < p ? enc[x] : gl_neg(enc[0]);               // the half box below X^N wraps to -f(0)
+    }
+    *post_add = gl_mul(gl_from_i64(c), ctx->delta_half);
+    return FBS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// twiddles for the merged negacyclic NTT: fwd[i] = psi^bitrev(i), inv[i] = psi^-bitrev(i).
+// psi is the primitive 2N-th root of unity with psi^(N/32) = 8, so that the twiddles of the first
+// five butterfly stages are powers of two (2 has order 192 in Z_q^*).
+// ---------------------------------------------------------------------------------------------
+void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv) {
+    const uint32_t N = 1u << log_n;
+    uint64_t psi = gl_pow(7, (GQ - 1) / (2ull * N));
+    if (N >= 32) {
+        uint64_t hroot = gl_pow(psi, N / 32);   // order 64
+        uint64_t acc = hroot;
+        for (uint32_t f = 1; f < 64; f += 2) {
+            if (acc == 8) {
+                psi = gl_pow(psi, f);
+                break;
+            }
+            acc = gl_mul(acc, gl_mul(hroot, hroot));
+        }
+    }
+    const uint64_t psi_inv = gl_inv(psi);
+    fwd.assign(N, 1);
+    inv.assign(N, 1);
+    for (uint32_t i = 1; i < N; i++) {
+        uint32_t r = 0;
+        for (uint32_t b = 0; b < log_n; b++) r |= ((i >> b) & 1u) << (log_n - 1 - b);
+        fwd[i] = gl_pow(psi, r);
+        inv[i] = gl_pow(psi_inv, r);
+    }
+}
+
+}  // namespace fbs

@@ -1,0 +1,117 @@
+// Internal definitions shared by the host side (fbs_host.cpp, fbs_capi.cpp) and the HIP side
+// (fbs_kernels.hip) of libfbsexec.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/fbs_exec.h"
+#include "fbs_field.hpp"
+
+namespace fbs {
+
+// ---- randomness: ChaCha20 keyed by the context seed (spec in DESIGN.md) -----------------------
+enum Domain : uint64_t {
+    DOM_SK_LWE = 1, DOM_SK_GLWE = 2, DOM_BSK_MASK = 3, DOM_BSK_NOISE = 4,
+    DOM_KSK_MASK = 5, DOM_KSK_NOISE = 6, DOM_ENC_MASK = 7, DOM_ENC_NOISE = 8
+};
+inline uint64_t stream_id(Domain d, uint64_t sub) { return ((uint64_t)d << 56) | (sub & 0x00FFFFFFFFFFFFFFull); }
+void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count);
+int64_t noise_sample(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t sigma);
+
+// ---- launch descriptors ------------------------------------------------------------------------
+// A "gate" is one Bootstrap instruction; it is applied to samples [s_begin, s_begin+s_count) of its
+// source wire.  Wire w, sample s lives at base + (w*T + s)*ct_stride words.  slot arrays may be
+// null (identity), which is the plain batch API.
+struct GateView {
+    const uint64_t *in_base;
+    uint64_t *out_base;
+    const uint32_t *src_slot;   // [n_gates] or null
+    const uint32_t *dst_slot;   // [n_gates] or null
+    const uint32_t *table_ids;  // [n_gates] or null (table 0)
+    size_t T;                   // samples per wire in the buffers
+    size_t s_begin, s_count;    // sample range processed
+    uint32_t n_gates;
+};
+
+struct Profile {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[3];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double ms[3] = {0, 0, 0};
+    uint64_t launches[3] = {0, 0, 0};
+};
+
+}  // namespace fbs
+
+struct fbs_ctx {
+    fbs_params p{};
+    uint64_t seed = 0;
+    int device = 0;
+    uint32_t N = 0, D = 0, rows = 0;   // D = k*N, rows = (k+1)*l
+    uint32_t ksk_stride = 0;           // padded n+1
+    uint64_t delta_half = 0;
+    uint64_t g[16]{};                  // round(q / B^(lv+1))
+    uint64_t h[64]{};                  // round(q / 2^(gamma (v+1)))
+    mutable std::string err;
+    std::string devinfo;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+
+    bool have_keys = false;
+    std::vector<uint64_t> sk_lwe, sk_glwe, bsk, ksk;   // host copies, standard layout
+
+    uint64_t *d_bsk_hat = nullptr;   // [n][rows][k+1][N]  NTT domain, lane-interleaved, x N^-1
+    uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
+    uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
+    uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)
+    uint32_t *d_ms = nullptr;        // scratch: mod-switched small ciphertexts [capacity][n+1]
+    size_t ms_capacity = 0;
+    uint32_t *d_idx = nullptr;       // scratch for index arrays of the wires API
+    size_t idx_capacity = 0;
+
+    fbs::Profile prof;
+};
+
+struct fbs_tvset {
+    fbs_ctx *ctx = nullptr;
+    uint32_t n_tables = 0;
+    uint64_t *d_tvs = nullptr;        // [n_tables][N]
+    uint64_t *d_post = nullptr;       // [n_tables]
+    std::vector<uint64_t> post;       // host copy
+};
+
+namespace fbs {
+
+int set_error(const fbs_ctx *ctx, int code, const std::string &msg);
+#define FBS_HIP(ctx, call)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fbs::set_error(ctx, FBS_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// host side (fbs_host.cpp)
+void host_keygen(fbs_ctx *ctx);
+void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts);
+void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);
+int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64_t *tv, uint64_t *post_add);
+void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv);
+
+// device side (fbs_kernels.hip); all asynchronous on `stream`
+int dev_supported(const fbs_ctx *ctx);   // FBS_OK or error if no kernel instance for the params
+int dev_upload_keys(fbs_ctx *ctx);       // BSK -> NTT domain, KSK padded
+int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream);
+int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream);
+int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *d_dst,
+                const uint32_t *d_term_off, const uint32_t *d_srcs, const uint64_t *d_coefs,
+                const uint64_t *d_consts, hipStream_t stream);
+int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream);
+
+// profiling helpers
+void prof_begin(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t *e0, hipEvent_t *e1);
+void prof_end(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+
+}  // namespace fbs
