@@ -1,0 +1,75 @@
+"""Shared by the test modules: fixture loading and an oracle-backed program evaluator."""
+import glob
+import gzip
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def fixture_names(pattern="*"):
+    return sorted(os.path.basename(p)[:-len(".json.gz")] for p in glob.glob(os.path.join(GOLDEN, pattern + ".json.gz")))
+
+
+def _decode(v):
+    if "const" in v:
+        return int(v["const"])
+    if "bits" in v:
+        raw = np.frombuffer(bytes.fromhex(v["bits"]), np.uint8)
+        return np.unpackbits(raw)[:v["n"]].astype(np.int64)
+    return np.asarray(v["ints"], np.int64)
+
+
+_cache = {}
+
+
+def load_fixture(name):
+    if name not in _cache:
+        with gzip.open(os.path.join(GOLDEN, name + ".json.gz"), "rb") as f:
+            rec = json.loads(f.read().decode())
+        rec["inputs"] = {k: _decode(v) for k, v in rec["inputs"].items()}
+        rec["outputs"] = {k: _decode(v) for k, v in rec["outputs"].items()}
+        if rec.get("outputs_bitenv"):
+            rec["outputs_bitenv"] = {k: _decode(v) for k, v in rec["outputs_bitenv"].items()}
+        _cache[name] = rec
+    return _cache[name]
+
+
+def subsample(rec, T):
+    """First T samples of the harness inputs and of the expected outputs."""
+    ins = {k: v[:T] for k, v in rec["inputs"].items()}
+    outs = {k: (v if isinstance(v, int) else v[:T]) for k, v in rec["outputs"].items()}
+    return ins, outs
+
+
+def assert_outputs_equal(got, expected):
+    assert set(got.keys()) == set(expected.keys())
+    for k, e in expected.items():
+        g = got[k]
+        if isinstance(e, int):
+            assert isinstance(g, (int, np.integer)) or np.ndim(g) == 0, k
+            assert int(g) == e, k
+        else:
+            assert np.array_equal(np.asarray(g).reshape(-1), e), "output %s differs" % k
+
+
+def oracle_eval_program(orc, ops, outputs, in_cts):
+    """Run a program (oracle.lut_oracle.read_fbs form) on ciphertexts with the C oracle.
+    in_cts: {input name: [T][ct_words]}.  Returns {wire name: [T][ct_words]} for all wires."""
+    wires = dict(in_cts)
+    T = len(next(iter(in_cts.values()))) if in_cts else 1
+    tv_cache = {}
+    for op in ops:
+        if op[0] == "lin":
+            _, name, terms, const = op
+            out = np.empty((T, orc.ctw), np.uint64)
+            for s in range(T):
+                out[s] = orc.lincomb([wires[src][s] for _, src in terms], [c for c, _ in terms], const)
+            wires[name] = out
+        else:
+            _, name, src, table = op
+            res, _ = orc.bootstrap_batch(wires[src], [table], None)
+            wires[name] = res
+    return wires

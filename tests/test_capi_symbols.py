@@ -1,0 +1,62 @@
+"""The C-ABI shared library loads on a GPU-less host, exports exactly what include/fbs_exec.h declares,
+and refuses to compute without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fbs_exec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fbs_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from tfhe_fbs_map_amd import _native
+    assert declared_symbols() == sorted(_native.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    from tfhe_fbs_map_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_library_carries_gfx950_code_only():
+    from tfhe_fbs_map_amd import _native
+    blob = open(_native.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"gfx1100"):
+        assert other not in blob
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tfhe_fbs_map_amd import Context, FbsError, Params
+    with pytest.raises(FbsError) as e:
+        Context(Params())
+    assert e.value.code in (-2, -1) and "HIP" in str(e.value) or "device" in str(e.value)
+
+
+def test_bad_parameters_rejected_before_touching_the_device():
+    from tfhe_fbs_map_amd import Context, FbsError, Params
+    for bad in (Params(k=2), Params(log_n_poly=13), Params(l_bsk=5, beta_bsk=7), Params(p_msg=0)):
+        with pytest.raises(FbsError) as e:
+            Context(bad)
+        assert e.value.code == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tfhe_fbs_map_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("tfhe_oracle.h)", ""), f

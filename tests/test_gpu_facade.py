@@ -1,0 +1,78 @@
+"""Drop-in behaviour: a mapped program written by the REFERENCE (fixture text), read back and evaluated
+with `LutExecEnv.eval` on the GPU, returns what the reference's cleartext `eval` returned -- the
+reference's own self-check (fbs_mapper/map_circuit.py:137-180) with ciphertexts in the middle."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_outputs_equal, fixture_names, load_fixture, subsample
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg15():
+    from tfhe_fbs_map_amd import ExecConfig
+    return ExecConfig()          # p picked per program, default parameter set for that p
+
+
+def run(name, T, cfg):
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture(name)
+    ins, expect = subsample(rec, T)
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"], merge_linear_prods=name != "edge_nomerge")
+    got = env.eval(ins, config=cfg)
+    assert_outputs_equal(got, expect)
+    return got
+
+
+@pytest.mark.parametrize("name", ["demo_fbs_exec_env", "demo_map_to_fbs__basic", "demo_map_to_fbs__naive",
+                                  "demo_map_to_fbs__search", "edge_outputs", "edge_nomerge"])
+def test_demos_and_edges(name, cfg15):
+    run(name, 64, cfg15)
+
+
+SMALL = [n for n in fixture_names() if n.split("__")[0] in
+         ("ascon_lut", "aes_sbox", "simon_iter", "2_input_gates", "full_adder", "half_adder", "aoi21", "oai21",
+          "kreyvium_iter_v1", "trivium_iter_v2") and ("_p7" in n or "_p15" in n or "_p3" in n or "_p2" in n)]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_reference_generated_circuits(name, cfg15):
+    run(name, 32, cfg15)
+
+
+def test_builder_then_eval_like_the_reference_demo(cfg15):
+    from tfhe_fbs_map_amd import LutExecEnv
+    env = LutExecEnv()
+    a, b, c = env.input("a"), env.input("b"), env.const(1)
+    e = env.linear([1, 1], [c, env.linear([1, 2], [a, b])])
+    f = env.bootstrap(e, [1, 0, 1, 1, 0])
+    g = env.linear([2, 1], [a, f])
+    h = env.bootstrap(g, [1, 1, 0, 2])
+    env.output("f", f); env.output("g", g); env.output("h", h)
+    out = env.eval({"a": [1, 0], "b": [1, 0], "c": [1, 0]}, config=cfg15)
+    assert {k: list(v) for k, v in out.items()} == {"f": [0, 0], "g": [2, 0], "h": [0, 1]}
+
+
+def test_config1_adder128(cfg15):
+    run("adder128__search_p15", 16, cfg15)
+
+
+def test_config3_multiplier_full_harness(cfg15):
+    """BASELINE config 3: 16x16 multiplier stand-in @15, all 1000 harness samples: 482 000 bootstraps."""
+    out = run("mul16__search_p15", 1000, cfg15)
+    ins = load_fixture("mul16__search_p15")["inputs"]
+    a = sum(ins["a%d" % i].astype(object) << i for i in range(16))
+    b = sum(ins["b%d" % i].astype(object) << i for i in range(16))
+    prod = sum(out["p%d" % i].astype(object) << i for i in range(32))
+    assert np.all(prod == a * b)
+
+
+def test_config4_wide_levels(cfg15):
+    run("trivium_stream_short128__search_p15", 64, cfg15)
+
+
+def test_config5_p31_on_n2048():
+    from tfhe_fbs_map_amd import ExecConfig
+    run("adder128__search_p31", 8, ExecConfig())          # params_for(31) -> N = 2048
+    run("full_adder__naive_p31", 32, ExecConfig())

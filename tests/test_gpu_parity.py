@@ -1,0 +1,212 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes -> libfbsexec.so), against the CPU
+oracle on identical keys and ciphertexts -- bit-exact for every word -- and, at BASELINE's full batch
+size, through size-independent properties (decrypt == table lookup, determinism)."""
+import numpy as np
+import pytest
+
+from oracle import lut_oracle, tfhe_oracle as orc
+from tests.helpers import load_fixture, oracle_eval_program, subsample
+
+pytestmark = pytest.mark.gpu
+
+MODES = [
+    [0, 1, 1, 0, 1, 0, 0],                               # len <= p
+    [0, 1, 2, 3, 2, 1, 0],                               # multi-valued
+    [0, 1],                                              # shorter than p
+    [0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1],          # mode 1 (map_to_fbs.py:91)
+    [0, 0, 0, 1, 1, 0, 1, 0, 0, 0],                      # mode 2 (:93)
+    [1, 1, 1, 0, 0, 1, 0, 1, 1, 1],                      # mode 3 (:95)
+]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from tfhe_fbs_map_amd import _native
+    return _native
+
+
+@pytest.fixture(scope="module")
+def toy_pair(nat, toy_params):
+    ctx = nat.Context(toy_params, seed=9)
+    return ctx, orc.Oracle(toy_params, seed=9)
+
+
+@pytest.fixture(scope="module")
+def p1024_pair(nat):
+    prm = nat.Params()
+    ctx = nat.Context(prm, seed=1)
+    return ctx, orc.Oracle(prm, seed=1)
+
+
+def test_device_is_gfx950(toy_pair):
+    assert toy_pair[0].device_info.startswith("gfx950")
+
+
+@pytest.mark.parametrize("log_n", [8, 9, 10, 11])
+def test_device_ntt_product(nat, toy_params, log_n):
+    ctx = nat.Context(toy_params.replace(log_n_poly=log_n, n=2), seed=2)
+    rng = np.random.default_rng(log_n)
+    N = 1 << log_n
+    for trial in range(3):
+        a = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64)
+        b = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64)
+        if trial == 2:                    # extreme residues
+            a[:] = nat.GOLDILOCKS - 1
+            b[::2] = nat.GOLDILOCKS - 1
+        assert np.array_equal(ctx.debug_polymul(a, b), orc.polymul_ntt(a, b))
+    if log_n == 8:
+        assert np.array_equal(ctx.debug_polymul(a, b), orc.polymul_schoolbook(a, b))
+
+
+def test_keys_and_encryption_identical_to_oracle(toy_pair, p1024_pair):
+    for ctx, o in (toy_pair, p1024_pair):
+        mine, theirs = ctx.export_keys(), o.keys()
+        for k in mine:
+            assert np.array_equal(mine[k], theirs[k]), k
+        msgs = np.arange(20) % (2 * ctx.params.p_msg)
+        assert np.array_equal(ctx.encrypt(msgs, 77), o.encrypt(msgs, 77))
+        assert np.array_equal(ctx.decrypt(o.encrypt(msgs, 5)), msgs)
+
+
+@pytest.mark.parametrize("log_n", [8, 9, 10, 11])
+def test_bootstrap_bit_exact_all_sizes(nat, toy_params, log_n):
+    prm = toy_params.replace(log_n_poly=log_n)
+    ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
+    msgs = np.concatenate([np.arange(len(t)) for t in MODES])
+    ids = np.concatenate([np.full(len(t), i) for i, t in enumerate(MODES)]).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=11)
+    got = ctx.bootstrap_batch(ctx.tvset(MODES), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, MODES, ids)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(t) for t in MODES]))
+
+
+def test_bootstrap_bit_exact_p1024(p1024_pair):
+    ctx, o = p1024_pair
+    rng = np.random.default_rng(42)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
+    msgs = rng.integers(0, 15, 12)
+    ids = (np.arange(12) % 16).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=1)
+    got = ctx.bootstrap_batch(ctx.tvset(tables), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, tables, ids)
+    assert np.array_equal(got, ref)
+
+
+def test_edge_ciphertexts(toy_pair):
+    """zero rotation amounts, trivial ciphertexts, body-only ciphertexts, maximal residues"""
+    ctx, o = toy_pair
+    ctw = ctx.params.ct_words
+    cts = np.zeros((5, ctw), np.uint64)
+    cts[1, -1] = 3 * 2 * o.delta_half                     # trivial encryption of 3
+    cts[2, :] = orc.Q - 1                                 # all words maximal
+    cts[3, ::2] = orc.Q - 1
+    cts[4, -1] = orc.Q - 1
+    tables = [[0, 1, 2, 3, 2, 1, 0]]
+    got = ctx.bootstrap_batch(ctx.tvset(tables), cts)
+    ref, _ = o.bootstrap_batch(cts, tables)
+    assert np.array_equal(got, ref)
+    assert ctx.decrypt(got)[1] == 3
+
+
+def test_empty_and_ragged_batches(toy_pair):
+    ctx, o = toy_pair
+    tv = ctx.tvset([[0, 1, 1, 0, 1, 0, 0]])
+    assert ctx.bootstrap_batch(tv, np.zeros((0, ctx.params.ct_words), np.uint64)).shape[0] == 0
+    for count in (1, 7, 9, 17):                           # not multiples of the key-switch tile (8)
+        msgs = np.arange(count) % 7
+        cts = ctx.encrypt(msgs, nonce0=count)
+        got = ctx.bootstrap_batch(tv, cts)
+        ref, _ = o.bootstrap_batch(cts, [[0, 1, 1, 0, 1, 0, 0]])
+        assert np.array_equal(got, ref)
+
+
+def test_errors_are_codes_not_crashes(nat, toy_pair):
+    ctx, _ = toy_pair
+    with pytest.raises(nat.FbsError) as e:
+        ctx.tvset([[0, 1, 0, 1, 0, 0, 0, 1, 1, 0]])      # violates the negacyclic contract at p = 7
+    assert e.value.code == -4
+    with pytest.raises(nat.FbsError) as e:
+        ctx.tvset([list(range(15))])                      # longer than 2p
+    assert e.value.code == -4
+    tv = ctx.tvset([[0, 1, 1, 0, 1, 0, 0]])
+    with pytest.raises(nat.FbsError) as e:
+        ctx.bootstrap_batch(tv, ctx.encrypt([1, 2]), [0, 5])
+    assert e.value.code == -1
+    fresh = nat.Context(ctx.params, seed=1, keygen=False)
+    with pytest.raises(nat.FbsError) as e:
+        fresh.encrypt([1])
+    assert e.value.code == -3
+
+
+def test_full_batch_properties_p1024(p1024_pair):
+    """BASELINE config 2 at full size (1024 independent FBS, 16 tables): decrypt == table lookup for every
+    sample, two runs are bit-identical, and a permuted batch gives the permuted result."""
+    ctx, _ = p1024_pair
+    rng = np.random.default_rng(42)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
+    B = 1024
+    msgs = rng.integers(0, 15, B)
+    ids = (np.arange(B) % 16).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=0)
+    tv = ctx.tvset(tables)
+    out1 = ctx.bootstrap_batch(tv, cts, ids)
+    assert np.array_equal(ctx.decrypt(out1), [tables[i][m] for i, m in zip(ids, msgs)])
+    out2 = ctx.bootstrap_batch(tv, cts, ids)
+    assert np.array_equal(out1, out2)
+    perm = rng.permutation(B)
+    out3 = ctx.bootstrap_batch(tv, cts[perm], ids[perm])
+    assert np.array_equal(out3, out1[perm])
+    assert out1.max() < orc.Q                               # everything stored is canonical
+
+
+def test_lincomb_kernel_matches_oracle(nat, toy_pair):
+    import torch
+    ctx, o = toy_pair
+    ctw = ctx.params.ct_words
+    T = 5
+    msgs = np.arange(3 * T).reshape(3, T) % 2
+    wires = np.zeros((6, T, ctw), np.uint64)
+    wires[:3] = ctx.encrypt(msgs, nonce0=50)
+    d = torch.from_numpy(wires.view(np.int64)).cuda()
+    # wire3 = 2*w0 - w1 + 3 ; wire4 = -1*w2 + 1 ; wire5 = w0 + w1 + w2 (three outputs, ragged term lists)
+    dst, off, srcs = [3, 4, 5], [0, 2, 3, 6], [0, 1, 2, 0, 1, 2]
+    coefs, consts = [2, -1, -1, 1, 1, 1], [3, 1, 0]
+    ctx.lincomb_dev(d.data_ptr(), T, dst, off, srcs, coefs, consts)
+    ctx.sync()
+    got = d.cpu().numpy().view(np.uint64)
+    for g in range(3):
+        for s in range(T):
+            terms = range(off[g], off[g + 1])
+            ref = o.lincomb([wires[srcs[t], s] for t in terms], [coefs[t] for t in terms], consts[g])
+            assert np.array_equal(got[dst[g], s], ref)
+
+
+@pytest.mark.parametrize("name,T", [("demo_fbs_exec_env", 2), ("edge_outputs", 5), ("edge_nomerge", 5),
+                                    ("full_adder__search_p7", 6), ("adder8__search_p7", 3),
+                                    ("aes_sbox__search_p7", 2), ("mul4__naive_p7", 2)])
+def test_program_ciphertexts_bit_exact(nat, toy_params, name, T):
+    """Whole program on the GPU executor (fbs_eval: level-batched lincomb + bootstrap kernels) vs the oracle
+    evaluating the same instruction list one ciphertext at a time: every output word identical."""
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture(name)
+    ops, outs = lut_oracle.read_fbs(rec["fbs"])
+    tables = [op[3] for op in ops if op[0] == "boot"]
+    p = max(7, max(len(t) for t in tables))
+    prm = toy_params.replace(p_msg=p)
+    ctx, o = nat.Context(prm, seed=6), orc.Oracle(prm, seed=6)
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"], merge_linear_prods=name != "edge_nomerge")
+    low = env.lower()
+    ins, expect = subsample(rec, T)
+    bits = np.stack([ins[n] for n in low["input_names"]])
+    cts = ctx.encrypt(bits, nonce0=9)
+    prog = nat.Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                       low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    got = prog.eval(cts, T)
+    wires = oracle_eval_program(o, ops, outs, {n: cts[i] for i, n in enumerate(low["input_names"])})
+    for k, (out_name, src) in enumerate(outs):
+        if src in ("0", "1"):
+            assert ctx.decrypt(got[k]).tolist() == [int(src)] * T
+        else:
+            assert np.array_equal(got[k], wires[src]), out_name
+            assert np.array_equal(ctx.decrypt(got[k]), expect[out_name])

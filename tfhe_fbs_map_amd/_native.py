@@ -88,6 +88,12 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  tfhe_fbs_map_amd has no CPU fallback.")
+    # PyTorch ships its own copy of the HIP runtime; if it is going to be used in this process (device
+    # tensors, RCCL) it has to be the first one loaded, or torch later finds "No HIP GPUs".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
     sig = {

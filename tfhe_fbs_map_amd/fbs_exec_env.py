@@ -1,0 +1,492 @@
+"""Drop-in for the reference's `fbs_mapper/fbs_exec_env.py`: same class, same builder and
+serialiser surface, but `eval` runs the program HOMOMORPHICALLY on an MI355X.
+
+Reference interface mirrored here (file:line in /root/reference/fbs_mapper/fbs_exec_env.py):
+  LutExecEnv(merge_linear_prods=True) :63      .input :102   .const :105   .linear :131
+  .bootstrap :147   .output :154   .print :158   .write_lbf :170   .eval :208
+  .remove_dangling_nodes :231   .stats :245   node classes Node/Const/Input/LinearProd/Bootstrap :12-61
+  attributes instructions / outputs / max_val / instr_cache :65-69
+
+`eval(input_values)` keeps the reference's contract -- dict of 0/1 arrays in, dict of integer
+arrays out (python ints for constant outputs) -- by encrypting the inputs, running every
+LinearProd / Bootstrap on ciphertexts through libfbsexec.so (ctypes, C ABI in
+include/fbs_exec.h) and decrypting the outputs.  There is no cleartext or CPU path in this
+module; without the GPU library it raises.
+
+Additions with no counterpart in the reference: `parse_fbs` / `parse_lbf` (the reference only
+writes those formats, :158-206), `schedule()` (bootstrap levels), `lower()` (flat program for
+the C ABI) and the `ExecConfig` that picks parameters and caches keyed contexts.
+The north-star name `FbsExecEnv` is an alias of `LutExecEnv`.
+"""
+from __future__ import annotations
+
+import logging
+import re
+import sys
+import textwrap
+from dataclasses import dataclass, field
+
+import numpy as np
+
+__all__ = ["LutExecEnv", "FbsExecEnv", "ExecConfig", "parse_fbs", "parse_lbf", "min_fbs_size", "table_is_valid"]
+
+
+# --------------------------------------------------------------------------------------------
+# negacyclic table contract (reference fbs_mapper/map_to_fbs.py:81-98)
+# --------------------------------------------------------------------------------------------
+def table_is_valid(table, p):
+    """Can one functional bootstrap with plaintext modulus `p` evaluate `table`?
+    Yes when it fits the half torus (len <= p), or when it is at most 2p long and the value met
+    at x + p is `c - table[x]` for one constant c (c = 1, 0, 2 are the reference's three modes)."""
+    L = len(table)
+    if L <= p:
+        return True
+    if L > 2 * p:
+        return False
+    c = table[0] + table[p]
+    return all(table[i] + table[i + p] == c for i in range(L - p))
+
+
+def min_fbs_size(tables, at_least=2):
+    """Smallest p for which every table is evaluable."""
+    p = max(2, at_least)
+    longest = max((len(t) for t in tables), default=1)
+    while p < longest and not all(table_is_valid(t, p) for t in tables):
+        p += 1
+    return p
+
+
+# --------------------------------------------------------------------------------------------
+# execution configuration (no counterpart in the reference)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ExecConfig:
+    """How `LutExecEnv.eval` reaches the GPU.  `fbs_size=None` picks the smallest p that can
+    evaluate every table of the program; `params=None` picks the default set for that p."""
+    fbs_size: int | None = None
+    params: object | None = None          # tfhe_fbs_map_amd.Params (p_msg is overridden by fbs_size)
+    seed: int = 1
+    device: int = 0
+    nonce0: int = 0
+    _contexts: dict = field(default_factory=dict, repr=False)
+
+    def context_for(self, p):
+        from . import _native as nat
+        from .params import params_for
+        prm = (self.params or params_for(p)).replace(p_msg=p)
+        key = (prm, self.seed, self.device)
+        ctx = self._contexts.get(key)
+        if ctx is None:
+            ctx = self._contexts[key] = nat.Context(prm, seed=self.seed, device=self.device)
+        return ctx
+
+
+class LutExecEnv:
+    # ---- node types (names, attributes, __str__ forms as in the reference :12-61) -------------
+    class Node:
+        def __init__(self, name):
+            self.name = name
+
+        def __eq__(self, other):
+            return repr(self) == repr(other)
+
+        def __hash__(self):
+            return hash(self.name)
+
+    class Const(Node):
+        def __init__(self, value):
+            LutExecEnv.Node.__init__(self, str(value))
+            self.value = value
+
+        def __str__(self):
+            return str(self.value)
+
+    class Input(Node):
+        def __str__(self):
+            return "Input(%s)" % self.name
+
+    class LinearProd(Node):
+        def __init__(self, name, coef_vals, const_coef=0):
+            LutExecEnv.Node.__init__(self, name)
+            if not all(isinstance(v, LutExecEnv.Node) for _, v in coef_vals):
+                raise AssertionError("Expected 'Node' type")
+            self.coef_vals = coef_vals
+            self.const_coef = const_coef
+
+        def __str__(self):
+            terms = " + ".join("%s * %s" % (c, v.name) for c, v in self.coef_vals)
+            tail = "+ %s" % self.const_coef if self.const_coef != 0 else ""
+            return terms + " " + tail          # the reference leaves a trailing blank when const is 0
+
+    class Bootstrap(Node):
+        def __init__(self, name, val, table):
+            LutExecEnv.Node.__init__(self, name)
+            if not isinstance(table, list):
+                raise AssertionError("Expected list")
+            if not isinstance(val, LutExecEnv.Node):
+                raise AssertionError("Expected LutExecEnv.Node")
+            self.table = table
+            self.val = val
+
+        def __str__(self):
+            return "Bootstrap(%s, %s)" % (self.val.name, self.table)
+
+    #: shared default; assign a new ExecConfig (class- or instance-level) to change device/params
+    exec_config = ExecConfig()
+
+    # ---- construction -------------------------------------------------------------------------
+    def __init__(self, merge_linear_prods=True):
+        self._unique_id = 0
+        self.instructions = []
+        self.outputs = {}
+        self._merge_linear_prods = merge_linear_prods
+        self.max_val = {}
+        self.instr_cache = {}
+        self.logger = logging.getLogger("LutExecEnv")
+        self._lowered = None
+
+    def _new_id(self):
+        self._unique_id += 1
+        return "m%d" % self._unique_id
+
+    def _bound(self, instr):
+        """Upper bound of the value an instruction can take (lower bound is 0 by construction)."""
+        if isinstance(instr, LutExecEnv.Input):
+            return 1
+        if isinstance(instr, LutExecEnv.LinearProd):
+            return instr.const_coef + sum(max(0, c * self.max_val[v.name]) for c, v in instr.coef_vals)
+        if isinstance(instr, LutExecEnv.Bootstrap):
+            assert min(instr.table) == 0
+            return max(instr.table)
+        raise AssertionError("Unknown instruction")
+
+    def _add_instr(self, instr):
+        key = str(instr)
+        hit = self.instr_cache.get(key)
+        if hit is not None:                       # common-subexpression: same text, same node
+            return hit
+        assert instr.name not in self.max_val, "Error"
+        self.instr_cache[key] = instr
+        self.instructions.append(instr)
+        self.max_val[instr.name] = self._bound(instr)
+        self._lowered = None
+        return instr
+
+    def input(self, input_id):
+        return self._add_instr(LutExecEnv.Input(input_id))
+
+    def const(self, value):
+        return LutExecEnv.Const(value)
+
+    def linear(self, coefs, vals, const_coef=0):
+        terms = []
+        for coef, val in zip(coefs, vals):
+            assert isinstance(val, LutExecEnv.Node), "Expected LutExecEnv.Node"
+            if isinstance(val, LutExecEnv.LinearProd) and self._merge_linear_prods:
+                terms.extend((coef * c, v) for c, v in val.coef_vals)      # inline the inner combination
+                const_coef += coef * val.const_coef
+            elif isinstance(val, LutExecEnv.Const):
+                const_coef += coef * val.value
+            else:
+                terms.append((coef, val))
+        return self._add_instr(LutExecEnv.LinearProd(self._new_id(), terms, const_coef))
+
+    def bootstrap(self, val, table):
+        assert isinstance(val, LutExecEnv.Node), "Expected LutExecEnv.Node"
+        assert isinstance(table, list), "Expected list"
+        assert len(table) == self.max_val[val.name] + 1, "%s vs %s %s" % (table, val.name, self.max_val[val.name])
+        return self._add_instr(LutExecEnv.Bootstrap(self._new_id(), val, table))
+
+    def output(self, name, val):
+        assert isinstance(val, LutExecEnv.Node), "Expected LutExecEnv.Node"
+        self.outputs[name] = val
+        self._lowered = None
+
+    # ---- serialisers (formats of the reference :158-206) ----------------------------------------
+    def print(self, os=sys.stdout, show_inputs=False, show_outputs=False):
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Input) and not show_inputs:
+                continue
+            print("%s = %s" % (instr.name, instr), file=os)
+        if show_outputs:
+            for name, val in self.outputs.items():
+                print("Output %s = %s" % (name, val.name), file=os)
+
+    def write_lbf(self, os=sys.stdout):
+        def wrapped(line):
+            return " \\\n ".join(textwrap.wrap(line))
+
+        names = [i.name for i in self.instructions if isinstance(i, LutExecEnv.Input)]
+        print(wrapped(".inputs " + " ".join(names)), file=os)
+        print(wrapped(".outputs " + " ".join(str(k) for k in self.outputs)), file=os)
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Input):
+                continue
+            if isinstance(instr, LutExecEnv.LinearProd):
+                ordered = sorted(instr.coef_vals, key=lambda cv: cv[1].name)
+                print(".lincomb %s %s" % (" ".join(v.name for _, v in ordered), instr.name), file=os)
+                const = str(instr.const_coef) if instr.const_coef != 0 else ""
+                print("%s %s" % (" ".join(str(c) for c, _ in ordered), const), file=os)
+            elif isinstance(instr, LutExecEnv.Bootstrap):
+                print(".bootstrap %s %s" % (instr.val.name, instr.name), file=os)
+                print("".join(str(t) for t in instr.table), file=os)
+            else:
+                raise AssertionError("Unknown instruction")
+        for out, val in self.outputs.items():
+            print(".lincomb %s %s" % (val.name, out), file=os)
+            print("1", file=os)
+
+    # ---- analysis --------------------------------------------------------------------------------
+    def remove_dangling_nodes(self):
+        live = {v.name for v in self.outputs.values()}
+        for instr in reversed(self.instructions):
+            if instr.name not in live:
+                continue
+            if isinstance(instr, LutExecEnv.LinearProd):
+                live.update(v.name for _, v in instr.coef_vals)
+            elif isinstance(instr, LutExecEnv.Bootstrap):
+                live.add(instr.val.name)
+        self.instructions = [i for i in self.instructions if i.name in live]
+        self._lowered = None
+
+    def stats(self):
+        count = dict(inp=0, lin=0, boot=0)
+        widest = 0
+        norm2 = {}
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Input):
+                count["inp"] += 1
+                norm2[instr.name] = 1
+            elif isinstance(instr, LutExecEnv.LinearProd):
+                count["lin"] += 1
+                norm2[instr.name] = sum(c * c * norm2[v.name] for c, v in instr.coef_vals)
+            elif isinstance(instr, LutExecEnv.Bootstrap):
+                count["boot"] += 1
+                widest = max(widest, len(instr.table))
+                norm2[instr.name] = 1          # a bootstrap resets the noise
+            else:
+                raise AssertionError("Unknown instruction")
+        return dict(nb_inp=count["inp"], nb_linprod=count["lin"], nb_bootstrap=count["boot"], max_lut_size=widest,
+                    norm2_linprod=max(norm2.values()), nb_out=len(self.outputs))
+
+    def tables(self):
+        return [i.table for i in self.instructions if isinstance(i, LutExecEnv.Bootstrap)]
+
+    def schedule(self):
+        """Bootstrap levels: level(input)=0, level(LinearProd)=max over its sources,
+        level(Bootstrap)=level(source)+1.  Returns (levels: name->int, depth, widths per level)."""
+        level = {"0": 0, "1": 0}
+        widths = {}
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Input):
+                level[instr.name] = 0
+            elif isinstance(instr, LutExecEnv.LinearProd):
+                level[instr.name] = max((level[v.name] for _, v in instr.coef_vals), default=0)
+            else:
+                lv = level[instr.val.name] + 1
+                level[instr.name] = lv
+                widths[lv] = widths.get(lv, 0) + 1
+        depth = max(widths, default=0)
+        return level, depth, [widths.get(l, 0) for l in range(1, depth + 1)]
+
+    # ---- lowering to the C ABI's flat program ------------------------------------------------------
+    def lower(self):
+        """Flat arrays of `fbs_program_desc` (include/fbs_exec.h) plus the distinct tables."""
+        if self._lowered is not None:
+            return self._lowered
+        inputs = [i for i in self.instructions if isinstance(i, LutExecEnv.Input)]
+        body = [i for i in self.instructions if not isinstance(i, LutExecEnv.Input)]
+        wire = {inp.name: k for k, inp in enumerate(inputs)}
+        for k, instr in enumerate(body):
+            wire[instr.name] = len(inputs) + k
+        kind, arg0, arg1, const_coef, term_coef, term_src = [], [], [], [], [], []
+        tables, table_id = [], {}
+        for instr in body:
+            if isinstance(instr, LutExecEnv.LinearProd):
+                kind.append(0)
+                arg0.append(len(term_src))
+                arg1.append(len(instr.coef_vals))
+                const = int(instr.const_coef)
+                for c, v in instr.coef_vals:
+                    if isinstance(v, LutExecEnv.Const):     # only reachable through hand-made nodes
+                        const += int(c) * int(v.value)
+                        arg1[-1] -= 1
+                        continue
+                    term_coef.append(int(c))
+                    term_src.append(wire[v.name])
+                const_coef.append(const)
+            else:
+                key = tuple(int(t) for t in instr.table)
+                if key not in table_id:
+                    table_id[key] = len(tables)
+                    tables.append(list(key))
+                kind.append(1)
+                arg0.append(wire[instr.val.name])
+                arg1.append(table_id[key])
+                const_coef.append(0)
+        out_names, out_wire = [], []
+        for name, node in self.outputs.items():
+            out_names.append(name)
+            out_wire.append(-1 - int(node.value) if isinstance(node, LutExecEnv.Const) else wire[node.name])
+        self._lowered = dict(input_names=[i.name for i in inputs], kind=kind, arg0=arg0, arg1=arg1,
+                             const_coef=const_coef, term_coef=term_coef, term_src=term_src, tables=tables,
+                             out_names=out_names, out_wire=out_wire)
+        return self._lowered
+
+    # ---- the hot path ------------------------------------------------------------------------------
+    def eval(self, input_values, config: ExecConfig | None = None):
+        """Reference contract (:208-229): {input name: array-like of bits} -> {output name: np.ndarray
+        of ints}; a constant output comes back as a python int.  Evaluated on ciphertexts on the GPU."""
+        from . import _native as nat
+        cfg = config or self.exec_config
+        low = self.lower()
+        p = cfg.fbs_size or min_fbs_size(low["tables"])
+        for t in low["tables"]:
+            assert table_is_valid(t, p), "table %s cannot be evaluated by one bootstrap at fbs_size %d" % (t, p)
+        ctx = cfg.context_for(p)
+
+        names = low["input_names"]
+        cols = [np.asarray(input_values[n]).reshape(-1) for n in names]
+        T = max((len(c) for c in cols), default=1)
+        bits = np.stack([np.broadcast_to(c, (T,)) for c in cols]).astype(np.int64) if cols else np.zeros((0, T), np.int64)
+        assert bits.size == 0 or (bits.min() >= 0 and bits.max() <= 1), "inputs are bits"
+
+        cache = getattr(ctx, "_programs", None)
+        if cache is None:
+            cache = ctx._programs = {}
+        prog = cache.get(id(low))
+        if prog is None:
+            tv = ctx.tvset(low["tables"])
+            prog = cache[id(low)] = (nat.Program(ctx, tv, len(names), low["kind"], low["arg0"], low["arg1"],
+                                                 low["const_coef"], low["term_coef"], low["term_src"],
+                                                 low["out_wire"]), low)
+        program = prog[0]
+        cts = ctx.encrypt(bits, nonce0=cfg.nonce0)
+        out = ctx.decrypt(program.eval(cts, T))
+        result = {}
+        for k, name in enumerate(low["out_names"]):
+            w = low["out_wire"][k]
+            result[name] = (-1 - w) if w < 0 else out[k].astype(int)
+        return result
+
+
+FbsExecEnv = LutExecEnv
+
+
+# --------------------------------------------------------------------------------------------
+# readers for the two text formats the reference emits (it has no reader of its own)
+# --------------------------------------------------------------------------------------------
+_TERM = re.compile(r"^(-?\d+) \* (\S+)$")
+_TABLE_ENTRY = re.compile(r"^(?:np\.int64\((-?\d+)\)|(-?\d+))$")
+
+
+class _Loader:
+    """Builds a LutExecEnv with the names given in the text (ids may have gaps: CSE consumed them)."""
+
+    def __init__(self, merge_linear_prods=True):
+        self.env = LutExecEnv(merge_linear_prods)
+        self.nodes = {}
+
+    def ref(self, name):
+        node = self.nodes.get(name)
+        if node is None:
+            if name in ("0", "1"):
+                return self.env.const(int(name))
+            node = self.nodes[name] = self.env.input(name)      # undefined name = primary input
+        return node
+
+    def define(self, node):
+        assert node.name not in self.nodes, "wire %s defined twice" % node.name
+        got = self.env._add_instr(node)
+        self.nodes[node.name] = got
+        m = re.fullmatch(r"m(\d+)", node.name)
+        if m:
+            self.env._unique_id = max(self.env._unique_id, int(m.group(1)))
+        return got
+
+
+def parse_fbs(text, inputs=None, merge_linear_prods=True):
+    """Read what `LutExecEnv.print(show_outputs=True)` wrote.  `inputs` optionally fixes the order of
+    the primary inputs (the printer omits them by default)."""
+    ld = _Loader(merge_linear_prods)
+    for name in inputs or ():
+        ld.ref(name)
+    for raw in text.splitlines():
+        line = raw.strip()
+        if not line:
+            continue
+        if line.startswith("Output "):
+            name, _, target = line[len("Output "):].partition(" = ")
+            ld.env.output(name, ld.ref(target.strip()))
+            continue
+        name, _, rhs = line.partition(" = ")
+        rhs = rhs.strip()
+        if rhs.startswith("Input("):
+            ld.ref(name)
+        elif rhs.startswith("Bootstrap("):
+            src, _, tab = rhs[len("Bootstrap("):-1].partition(", ")
+            entries = []
+            for e in tab.strip()[1:-1].split(","):
+                m = _TABLE_ENTRY.match(e.strip())
+                assert m, "bad table entry %r" % e
+                # numpy >= 2 leaks `np.int64(1)` reprs into the reference's tables; keep the flavour so
+                # that printing the program again gives the same text
+                entries.append(np.int64(m.group(1)) if m.group(1) is not None else int(m.group(2)))
+            src_node = ld.ref(src)
+            assert len(entries) == ld.env.max_val[src_node.name] + 1, "table length does not match %s" % src
+            ld.define(LutExecEnv.Bootstrap(name, src_node, entries))
+        else:
+            terms, const = [], 0
+            for piece in rhs.split(" + "):
+                piece = piece.strip()
+                m = _TERM.match(piece)
+                if m:
+                    terms.append((int(m.group(1)), ld.ref(m.group(2))))
+                else:
+                    const += int(piece)
+            ld.define(LutExecEnv.LinearProd(name, terms, const))
+    return ld.env
+
+
+def parse_lbf(text, merge_linear_prods=True):
+    """Read what `LutExecEnv.write_lbf` wrote."""
+    logical, pending = [], ""
+    for raw in text.splitlines():
+        if raw.rstrip().endswith("\\"):
+            pending += raw.rstrip()[:-1] + " "
+            continue
+        logical.append((pending + raw).strip())
+        pending = ""
+    ld = _Loader(merge_linear_prods)
+    outputs = []
+    k = 0
+    while k < len(logical):
+        words = logical[k].split()
+        k += 1
+        if not words:
+            continue
+        if words[0] == ".inputs":
+            for name in words[1:]:
+                ld.ref(name)
+        elif words[0] == ".outputs":
+            outputs = words[1:]
+        elif words[0] == ".lincomb":
+            *srcs, name = words[1:]
+            nums = [int(w) for w in logical[k].split()]
+            k += 1
+            if name in outputs and name not in ld.nodes and len(srcs) == 1 and nums == [1] and not re.fullmatch(r"m\d+", name):
+                ld.env.output(name, ld.ref(srcs[0]))            # the trailing "output = 1 * node" records
+                continue
+            if name in outputs and name in ld.nodes and len(srcs) == 1 and nums == [1]:
+                ld.env.output(name, ld.ref(srcs[0]))
+                continue
+            coefs, const = nums[:len(srcs)], (nums[len(srcs)] if len(nums) > len(srcs) else 0)
+            ld.define(LutExecEnv.LinearProd(name, [(c, ld.ref(s)) for c, s in zip(coefs, srcs)], const))
+        elif words[0] == ".bootstrap":
+            src, name = words[1], words[2]
+            entries = [int(ch) for ch in logical[k].strip()]
+            k += 1
+            ld.define(LutExecEnv.Bootstrap(name, ld.ref(src), entries))
+        else:
+            raise ValueError("unknown .lbf record: %s" % logical[k - 1])
+    return ld.env

@@ -1,0 +1,53 @@
+"""Parameter sets and a small noise model.
+
+The reference never fixes cryptographic parameters: it hands (precision p, squared 2-norm of the
+linear combinations) -- `stats()["norm2_linprod"]`, fbs_mapper/fbs_exec_env.py:245-276 -- to a patched
+concrete-optimizer (experiments/add_exec_estimates.py:9-16, experiments/concrete.patch:21-27) that is
+not available here.  This module is the stand-in: the BASELINE.md set P1024 and its N=2048 sibling,
+plus textbook CGGI variance formulas so a caller can see how many standard deviations of margin a
+(parameter set, p, norm2) combination has.  All variances are relative to q^2 (torus units).
+
+The default noise (sigma = 2^24 on a 2^64 modulus, i.e. 2^-40 relative) is REDUCED NOISE: it makes
+N=1024 correct for p=15 with generous margin but is far below what 128-bit security needs at these
+dimensions (~2^-25 at N=1024, which would not leave room for p=15).  Throughput does not depend on it.
+"""
+from __future__ import annotations
+
+import math
+
+from ._native import Params
+
+P1024 = Params()                                            # n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2
+P2048 = Params(n=630, log_n_poly=11, l_bsk=3, beta_bsk=7)   # p = 31 needs the wider accumulator
+
+
+def params_for(p: int, norm2: int | None = None) -> Params:
+    """Default set for plaintext modulus p: the modulus switch alone (n = 630) leaves about
+    N / (10.2 p) standard deviations between a value and the edge of its box, so p <= 16 fits
+    N = 1024 (>= 6 sigma) and p <= 32 wants N = 2048."""
+    base = P1024 if p <= 16 else P2048
+    return base.replace(p_msg=p)
+
+
+def variances(prm: Params):
+    """(blind-rotate output, key switch, modulus switch) variances in torus units."""
+    q = 2.0 ** 64
+    N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
+    B, b2 = 2.0 ** prm.beta_bsk, 2.0 ** prm.gamma_ksk
+    s_glwe, s_lwe = prm.sigma_glwe / q, prm.sigma_lwe / q
+    # external product: (k+1) l N digits of variance (B^2+2)/12 against key noise, plus the
+    # rounding of the decomposition (half an ulp of q/B^l) seen through a binary key
+    v_br = n * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
+    # key switch: unsigned digits in [0, 2^gamma): E[d^2] = (2^g - 1)(2^(g+1) - 1)/6
+    ed2 = (b2 - 1) * (2 * b2 - 1) / 6.0
+    v_ks = k * N * (t * ed2 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
+    v_ms = (1 + n / 2.0) / (12.0 * (2.0 * N) ** 2)
+    return v_br, v_ks, v_ms
+
+
+def margin_sigmas(prm: Params, norm2: float = 1.0) -> float:
+    """Half box width q/(4p) divided by the standard deviation of the phase that enters the
+    blind rotation, when the inputs of the linear combination are bootstrap outputs."""
+    v_br, v_ks, v_ms = variances(prm)
+    sigma = math.sqrt(norm2 * v_br + v_ks + v_ms)
+    return (1.0 / (4.0 * prm.p_msg)) / sigma
