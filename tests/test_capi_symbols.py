@@ -59,4 +59,5 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.replace("tfhe_oracle.h)", ""), f
+                # prose may mention the checker; code must not import, open or link it
+                assert not re.search(r"(import\s+oracle|from\s+oracle|oracle[./]|libtfhe_oracle|tfhe_oracle|lut_oracle|orc_)", src), f
