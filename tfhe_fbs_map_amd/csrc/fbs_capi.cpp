@@ -112,7 +112,9 @@ int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx 
         return set_error(nullptr, FBS_E_DEVICE, std::string("device is ") + prop.gcnArchName + "; this library carries gfx950 code only");
     ctx->cu_count = prop.multiProcessorCount;
     ctx->devinfo = std::string(prop.gcnArchName) + " " + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // a blocking stream: ordered with the legacy null stream, which is what PyTorch's default stream is --
+    // a caller that passes stream = NULL while using torch tensors still gets correct ordering
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault);
     if (e != hipSuccess) return set_error(nullptr, FBS_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     *out = ctx.release();
     return FBS_OK;

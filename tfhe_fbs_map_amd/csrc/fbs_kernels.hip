@@ -283,6 +283,100 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     }
 }
 
+// Same arithmetic, mapped the other way round: LANES are ciphertexts (64 per workgroup) and the key words a
+// wave needs are wave-uniform, so they arrive through the scalar cache (s_load_dwordx16) instead of being
+// re-fetched by every ciphertext tile: KSK traffic drops from (count/8) x 50 MB to (count/64) x 41 MB per
+// launch.  A workgroup owns COLS output columns; its four waves each take a quarter of the kN mask words
+// (more waves in flight to cover the scalar-load latency) and their 96-bit partial sums meet in LDS.
+// The rounded mask words are staged per tile in LDS, transposed on the way in so that both the global read
+// (along the ciphertext row) and the LDS read (along the ciphertexts) are contiguous.
+template <int COLS>
+__global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
+    constexpr int JT = 32;                       // mask words per wave per staging round
+    __shared__ uint32_t tile[4 * JT * 64];       // [slice][j in tile][ciphertext]; reused for the final reduction
+    static_assert(4 * JT * 64 >= 3 * COLS * 3 * 64, "reduction scratch must fit in the staging tile");
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t f0 = (size_t)blockIdx.x * 64;
+    const size_t f = f0 + lane;
+    const uint32_t col0 = blockIdx.y * COLS;
+    const uint32_t tg = a.t * a.gamma;
+    const uint32_t dmask = (1u << a.gamma) - 1u;
+    const uint32_t slice_len = (a.D + 3) / 4;    // mask words per wave
+
+    uint32_t acc0[COLS], acc1[COLS], acc2[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) acc0[c] = acc1[c] = acc2[c] = 0;
+
+    for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
+        __syncthreads();
+        // 256 threads stage 4 slices x JT words x 64 ciphertexts: consecutive threads read consecutive words
+        for (uint32_t idx = threadIdx.x; idx < 4 * JT * 64; idx += 256) {
+            const uint32_t jj = idx % JT, q = (idx / JT) % 64, sl = idx / (JT * 64);
+            const uint32_t j = sl * slice_len + r0 + jj;
+            uint32_t v = 0;
+            if (f0 + q < a.count && r0 + jj < slice_len && j < a.D) {
+                const uint64_t w = gate_in(a.gv, f0 + q, a.ct_words)[j];
+                v = (uint32_t)(((w >> (63 - tg)) + 1) >> 1);
+            }
+            tile[(sl * JT + jj) * 64 + q] = v;
+        }
+        __syncthreads();
+        for (uint32_t jj = 0; jj < JT; jj++) {
+            const uint32_t j = wave * slice_len + r0 + jj;
+            if (r0 + jj >= slice_len || j >= a.D) break;          // wave-uniform
+            const uint32_t ab = tile[(wave * JT + jj) * 64 + lane];
+            const uint64_t *krow = a.ksk + (size_t)j * a.t * a.stride + col0;   // wave-uniform address
+            for (uint32_t v = 0; v < a.t; v++) {
+                const uint32_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    const uint64_t kw = krow[(size_t)v * a.stride + c];
+                    const uint64_t lo = (uint64_t)d * (uint32_t)kw + acc0[c];
+                    acc0[c] = (uint32_t)lo;
+                    const uint64_t mid = (uint64_t)d * (uint32_t)(kw >> 32) + acc1[c] + (lo >> 32);
+                    acc1[c] = (uint32_t)mid;
+                    acc2[c] += (uint32_t)(mid >> 32);
+                }
+            }
+        }
+    }
+    // waves 1..3 park their partial sums; wave 0 adds them up (96-bit), folds mod q and mod-switches
+    __syncthreads();
+    if (wave) {
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            uint32_t *slot = tile + (((wave - 1) * COLS + c) * 3) * 64 + lane;
+            slot[0] = acc0[c];
+            slot[64] = acc1[c];
+            slot[128] = acc2[c];
+        }
+    }
+    __syncthreads();
+    if (wave || f >= a.count) return;
+    const uint32_t sh_ms = 64 - a.log2_2n - 1;
+    const uint32_t mask = (1u << a.log2_2n) - 1u;
+    const uint64_t body = gate_in(a.gv, f, a.ct_words)[a.D];
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        const uint32_t col = col0 + c;
+        if (col > a.n) break;
+        uint64_t lo = ((uint64_t)acc1[c] << 32) | acc0[c];
+        uint32_t hi = acc2[c];
+#pragma unroll
+        for (int w = 0; w < 3; w++) {
+            const uint32_t *slot = tile + ((w * COLS + c) * 3) * 64 + lane;
+            const uint64_t plo = ((uint64_t)slot[64] << 32) | slot[0];
+            const uint64_t s = lo + plo;
+            hi += slot[128] + (s < lo ? 1u : 0u);
+            lo = s;
+        }
+        const uint64_t sum = gl_canon(gl_reduce128(lo, hi));
+        const uint64_t r = gl_sub(col == a.n ? body : 0, sum);
+        a.ms[f * (a.n + 1) + col] = (uint32_t)(((r >> sh_ms) + 1) >> 1) & mask;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // blind rotation + sample extraction
 // ---------------------------------------------------------------------------------------------
@@ -512,7 +606,6 @@ int dev_upload_keys(fbs_ctx *ctx) {
 
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream) {
     const fbs_params &p = ctx->p;
-    constexpr int FB = 8;
     KsArgs a{};
     a.gv = gv;
     a.ksk = ctx->d_ksk;
@@ -526,11 +619,19 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     a.log2_2n = p.log_n_poly + 1;
     a.count = (size_t)gv.n_gates * gv.s_count;
     if (a.count == 0) return FBS_OK;
-    dim3 grid((unsigned)((a.count + FB - 1) / FB), ctx->ksk_stride / 256);
-    size_t shmem = (size_t)FB * ctx->D * sizeof(uint32_t);
     hipEvent_t e0, e1;
     prof_begin(ctx, 0, stream, &e0, &e1);
-    hipLaunchKernelGGL(k_keyswitch<FB>, grid, dim3(256), shmem, stream, a);
+    if (a.count >= 32) {
+        // lanes = ciphertexts: pays once a wave is at least half full
+        constexpr int COLS = 8;
+        dim3 grid((unsigned)((a.count + 63) / 64), (p.n + 1 + COLS - 1) / COLS);
+        hipLaunchKernelGGL(k_keyswitch_lanes<COLS>, grid, dim3(256), 0, stream, a);
+    } else {
+        constexpr int FB = 8;
+        dim3 grid((unsigned)((a.count + FB - 1) / FB), ctx->ksk_stride / 256);
+        size_t shmem = (size_t)FB * ctx->D * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_keyswitch<FB>, grid, dim3(256), shmem, stream, a);
+    }
     prof_end(ctx, 0, stream, e0, e1);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;
