@@ -12,8 +12,8 @@
  * "unpinned" against any third party; decrypted results ARE pinned against the
  * reference's cleartext goldens (tests/test_oracle_*.py).
  *
- * Deliberately simple: textbook twist + radix-2 cyclic NTT, __int128 modular
- * products, no tricks shared with the HIP kernels, so that agreement between
+ * Deliberately simple: textbook twist + radix-2 cyclic NTT, integer (__int128,
+ * Barrett) modular products -- the GPU computes the same residues with FP64 FMAs --, no tricks shared with the HIP kernels, so that agreement between
  * the two is evidence and not an echo.
  */
 #include "tfhe_oracle.h"
@@ -29,32 +29,28 @@ typedef __int128 i128;
 #define Q ORC_Q
 
 /* ------------------------------------------------------------------------ */
-/* field Z_q, q = 2^64 - 2^32 + 1                                            */
+/* field Z_q, q = 2^46 - 62*2^13 + 1 = 0x3FFFFFF84001 (prime, 2^14 | q-1)     */
 /* ------------------------------------------------------------------------ */
 /* branch-free forms: the data are random, so `if` mispredicts half the time */
 static inline uint64_t gl_add(uint64_t a, uint64_t b) {
-    uint64_t s = a + b;
-    uint64_t over = (uint64_t)0 - (uint64_t)((s < a) | (s >= Q)); /* a,b < q: at most one wrap */
-    return s - (Q & over);
+    uint64_t s = a + b; /* < 2^47 */
+    return s - (Q & ((uint64_t)0 - (uint64_t)(s >= Q)));
 }
 static inline uint64_t gl_sub(uint64_t a, uint64_t b) {
     uint64_t d = a - b;
     return d + (Q & ((uint64_t)0 - (uint64_t)(a < b)));
 }
 static inline uint64_t gl_neg(uint64_t a) { return (Q - a) & ((uint64_t)0 - (uint64_t)(a != 0)); }
-/* x mod q for x < 2^128, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod q):
- *   x = lo + 2^64*(h0 + 2^32*h1)  ->  lo - h1 + h0*(2^32 - 1) */
-static inline uint64_t gl_reduce128(u128 x) {
-    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
-    uint64_t h0 = hi & 0xFFFFFFFFu, h1 = hi >> 32;
-    uint64_t t = lo - h1;
-    t -= 0xFFFFFFFFull & ((uint64_t)0 - (uint64_t)(lo < h1)); /* wrapped: -2^64 = -(2^32-1) */
-    uint64_t u = h0 * 0xFFFFFFFFull;                           /* < 2^64 */
-    uint64_t r = t + u;
-    r += 0xFFFFFFFFull & ((uint64_t)0 - (uint64_t)(r < t));    /* carry: 2^64 = 2^32 - 1 */
-    return r - (Q & ((uint64_t)0 - (uint64_t)(r >= Q)));
+/* Barrett: x < q^2 < 2^92, mu = floor(2^92 / q); estimate floor(x/q) from the top bits, fix by <= 2 subtractions */
+#define BARRETT_MU ((uint64_t)(((u128)1 << 92) / Q))
+static inline uint64_t gl_reduce(u128 x) {
+    uint64_t qhat = (uint64_t)(((u128)(uint64_t)(x >> 45) * BARRETT_MU) >> 47);
+    uint64_t r = (uint64_t)x - qhat * Q; /* exact mod 2^64: the true remainder estimate is < 3q */
+    r -= Q & ((uint64_t)0 - (uint64_t)(r >= Q));
+    r -= Q & ((uint64_t)0 - (uint64_t)(r >= Q));
+    return r;
 }
-static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((u128)a * b); }
+static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce((u128)a * b); }
 static inline uint64_t gl_from_i64(int64_t v) { return v >= 0 ? (uint64_t)v % Q : Q - ((uint64_t)(-v) % Q); }
 
 uint64_t orc_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a % Q, b % Q); }
@@ -240,7 +236,11 @@ static void rand_fill(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *d
         dst[i] = (uint64_t)o[2 * w] | ((uint64_t)o[2 * w + 1] << 32);
     }
 }
-static inline uint64_t to_field(uint64_t r) { return r >= Q ? r - Q : r; }
+/* uniform residue from a 64-bit word: keep the top QBITS bits, fold once (bias 2^-27) */
+static inline uint64_t to_field(uint64_t r) {
+    r >>= 64 - ORC_QBITS;
+    return r >= Q ? r - Q : r;
+}
 
 /* Irwin-Hall(12) approximation of a centred Gaussian, integer only: twelve
  * 32-bit uniforms (six 64-bit words idx*6 .. idx*6+5), centred, variance 2^64,
@@ -283,7 +283,7 @@ static uint64_t round_div_q(uint64_t denom_log2) { /* round(q / 2^e) */
 }
 
 orc_ctx *orc_create(const orc_params *p, uint64_t seed) {
-    if (!p || p->l_bsk * p->beta_bsk > 62 || p->t_ksk * p->gamma_ksk > 62 || p->l_bsk > 16 || p->t_ksk > 64 ||
+    if (!p || p->l_bsk * p->beta_bsk > ORC_QBITS - 2 || p->t_ksk * p->gamma_ksk > ORC_QBITS - 2 || p->l_bsk > 16 || p->t_ksk > 64 ||
         p->log_n_poly < 2 || p->log_n_poly > 14 || p->k < 1 || p->p_msg < 1)
         return NULL;
     orc_ctx *c = calloc(1, sizeof *c);
@@ -488,7 +488,7 @@ void orc_keyswitch(const orc_ctx *c, const uint64_t *ct_big, uint64_t *ct_small)
     ct_small[n] = ct_big[d];
     for (uint32_t j = 0; j < d; j++) {
         /* closest multiple of q/2^(t*gamma): top t*gamma bits, rounded; unsigned digits */
-        uint64_t abar = ((ct_big[j] >> (63 - tg)) + 1) >> 1;
+        uint64_t abar = ((ct_big[j] >> (ORC_QBITS - 1 - tg)) + 1) >> 1;
         for (uint32_t v = 0; v < t; v++) {
             uint64_t dig = (abar >> (gam * (t - 1 - v))) & ((1ull << gam) - 1);
             if (!dig) continue;
@@ -499,7 +499,7 @@ void orc_keyswitch(const orc_ctx *c, const uint64_t *ct_big, uint64_t *ct_small)
 }
 
 void orc_modswitch(const orc_ctx *c, const uint64_t *ct_small, uint32_t *ms) {
-    uint32_t sh = 64 - c->p.log_n_poly - 2, mask = 2 * c->N - 1;
+    uint32_t sh = ORC_QBITS - c->p.log_n_poly - 2, mask = 2 * c->N - 1;
     for (uint32_t i = 0; i <= c->p.n; i++) ms[i] = (uint32_t)(((ct_small[i] >> sh) + 1) >> 1) & mask;
 }
 
@@ -516,7 +516,7 @@ static void decompose_poly(const orc_ctx *c, const uint64_t *poly, uint64_t *dig
     uint32_t N = c->N, l = c->p.l_bsk, beta = c->p.beta_bsk;
     uint64_t B = 1ull << beta, half = B >> 1;
     for (uint32_t j = 0; j < N; j++) {
-        uint64_t abar = ((poly[j] >> (63 - l * beta)) + 1) >> 1;
+        uint64_t abar = ((poly[j] >> (ORC_QBITS - 1 - l * beta)) + 1) >> 1;
         for (int lv = (int)l - 1; lv >= 0; lv--) {
             int64_t dg = (int64_t)(abar & (B - 1));
             abar >>= beta;

@@ -18,7 +18,7 @@
  *     un-vendored and unbuildable here.  This file restates the published TFHE
  *     algorithms (CGGI20 programmable bootstrap: key switch -> modulus switch
  *     -> blind rotation by CMUX/external product -> sample extraction) over the
- *     prime modulus q = 2^64 - 2^32 + 1 with an exact NTT, so "bit-exact" in
+ *     prime modulus q = 2^46 - 62*2^13 + 1 (64-bit words) with an exact NTT, so "bit-exact" in
  *     this project means GPU == this oracle, word for word.
  *
  * All vectors are canonical residues in [0, q).
@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define ORC_Q 0xFFFFFFFF00000001ULL
+#define ORC_Q 0x3FFFFFF84001ULL /* 2^46 - 62*2^13 + 1, prime; 2^14 divides q-1 */
+#define ORC_QBITS 46
 
 typedef struct {
     uint32_t n;          /* small LWE dimension                          */

@@ -10,7 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtfhe_oracle.so")
-Q = 0xFFFFFFFF00000001
+Q = 0x3FFFFFF84001          # 2^46 - 62*2^13 + 1
+QBITS = 46
 
 
 def build(force=False):
@@ -98,8 +99,8 @@ class Oracle:
             lib().orc_keygen(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.orc_destroy(self._h)
             self._h = None
 
     def key_sizes(self):

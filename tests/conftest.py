@@ -22,4 +22,4 @@ def pytest_configure(config):
 def toy_params():
     from tfhe_fbs_map_amd import Params
     # small n so that the CPU oracle does a bootstrap in milliseconds; real N so the GPU kernels are the shipped ones
-    return Params(n=12, log_n_poly=10, p_msg=7, sigma_lwe=1 << 20, sigma_glwe=1 << 20)
+    return Params(n=12, log_n_poly=10, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 8)

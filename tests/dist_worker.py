@@ -57,7 +57,7 @@ def main():
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     low = env.lower()
     p = max(7, max(len(t) for t in low["tables"]))
-    prm = Params(n=8, log_n_poly=8, p_msg=p, sigma_lwe=1 << 20, sigma_glwe=1 << 20)
+    prm = Params(n=8, log_n_poly=8, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=1 << 8)
     o = orc.Oracle(prm, seed=21)
     ins, expect = subsample(rec, T)
     cts = np.stack([o.encrypt(ins[n], nonce0=100 * i) for i, n in enumerate(low["input_names"])])

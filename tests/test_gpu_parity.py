@@ -48,11 +48,11 @@ def test_device_ntt_product(nat, toy_params, log_n):
     rng = np.random.default_rng(log_n)
     N = 1 << log_n
     for trial in range(3):
-        a = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64)
-        b = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64)
+        a = rng.integers(0, nat.MODULUS, N, dtype=np.uint64)
+        b = rng.integers(0, nat.MODULUS, N, dtype=np.uint64)
         if trial == 2:                    # extreme residues
-            a[:] = nat.GOLDILOCKS - 1
-            b[::2] = nat.GOLDILOCKS - 1
+            a[:] = nat.MODULUS - 1
+            b[::2] = nat.MODULUS - 1
         assert np.array_equal(ctx.debug_polymul(a, b), orc.polymul_ntt(a, b))
     if log_n == 8:
         assert np.array_equal(ctx.debug_polymul(a, b), orc.polymul_schoolbook(a, b))

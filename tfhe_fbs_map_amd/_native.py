@@ -13,9 +13,10 @@ from dataclasses import dataclass, asdict
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfbsexec.so")
+LIB_PATH = os.environ.get("FBS_LIB") or os.path.join(_HERE, "libfbsexec.so")   # FBS_LIB: kernel-variant experiments
 
-GOLDILOCKS = 0xFFFFFFFF00000001
+MODULUS = 0x3FFFFFF84001      # q = 2^46 - 62*2^13 + 1 (prime); ciphertext and NTT modulus, 64-bit words
+MODULUS_BITS = 46
 
 
 class FbsError(RuntimeError):
@@ -49,8 +50,8 @@ class Params:
     t_ksk: int = 8
     gamma_ksk: int = 2
     p_msg: int = 15
-    sigma_lwe: int = 1 << 24      # 2^-40 relative: reduced noise, see DESIGN.md "Noise"
-    sigma_glwe: int = 1 << 24
+    sigma_lwe: int = 1 << 6       # 2^-40 of q: reduced noise, see DESIGN.md "Noise"
+    sigma_glwe: int = 1 << 6
 
     @property
     def N(self):
@@ -159,7 +160,7 @@ class TvSet:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None) and self.ctx._h:
+        if getattr(self, "_h", None) and self.ctx._h and lib is not None:
             lib.fbs_tvset_destroy(self._h)
             self._h = None
 
@@ -187,7 +188,7 @@ class Program:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None) and self.ctx._h:
+        if getattr(self, "_h", None) and self.ctx._h and lib is not None:
             lib.fbs_program_destroy(self._h)
             self._h = None
 
@@ -212,7 +213,7 @@ class Context:
             raise FbsError(rc, lib.fbs_last_error(self._h).decode())
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None) and lib is not None:      # `lib` is None while the interpreter shuts down
             lib.fbs_ctx_destroy(self._h)
             self._h = None
 

@@ -1,0 +1,299 @@
+// Blind rotation + sample extraction (the hot kernel), the one-time key transform and a debug product, all on
+// the NTT of fbs_ntt.hpp.  gfx950 only.  Exact modular arithmetic on integer-valued doubles (fbs_field.hpp): the
+// FP64 FMA is the machine's widest exact multiplier; no MFMA, no tensor contraction -- every product is an
+// element-wise residue product.
+//
+// One functional bootstrap = one workgroup; GLWE component c (k = 1: mask, body) is owned by LANES lanes, each
+// holding E coefficients of the accumulator in VGPRs.  Per CMUX step: accumulator -> LDS, gather the rotated copy
+// (X^a), subtract, round to l*beta bits; per digit level: balanced digit -> forward NTT -> multiply-accumulate with
+// the two key polynomials of that row (lazy sums); hand the partner component its half through LDS; inverse NTT;
+// accumulate and canonicalise.  The bootstrapping-key row of a step (96 KB at P1024) is read once per workgroup
+// with 16-byte coalesced loads; all workgroups walk the key in step, so after the first touch it is served from
+// L2/MALL, not HBM.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "fbs_gate.hpp"
+#include "fbs_internal.hpp"
+#include "fbs_ntt.hpp"
+
+namespace fbs {
+
+struct BrArgs {
+    GateView gv;
+    const uint32_t *ms;      // [count][n+1], values in [0, 2N)
+    const double *bsk_hat;   // [n][rows][2][N]  centred, NTT order, times 1/N
+    const double *tw_fwd, *tw_inv;
+    const uint64_t *tvs;     // [tables][N]
+    const uint64_t *post;    // [tables]
+    uint32_t n, l, beta, ct_words;
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int LOGN, int LL>
+__global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__restrict__ src, double *__restrict__ dst,
+                                                           const double *__restrict__ tw_fwd, double n_inv, size_t polys) {
+    using W = PolyNtt<LOGN, LL>;
+    __shared__ double lds[2 * W::N];
+    const uint32_t t = threadIdx.x;
+    typename W::Xchg xc{lds, 0};
+    for (size_t p = blockIdx.x; p < polys; p += gridDim.x) {   // uniform trip count per workgroup
+        double x[W::E];
+#pragma unroll
+        for (int m = 0; m < W::E; m++) x[m] = fp_from_u64(src[p * W::N + W::template index_of<0>(t, m)]);
+        W::forward(x, xc, t, tw_fwd);
+#pragma unroll
+        for (int m = 0; m < W::E; m++) dst[p * W::N + W::key_word(t, m)] = fp_center(fp_mulmod(x[m], n_inv));
+    }
+}
+
+template <int LOGN, int LL>
+__global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const uint64_t *b, uint64_t *c, const double *tw_fwd,
+                                                     const double *tw_inv, double n_inv) {
+    using W = PolyNtt<LOGN, LL>;
+    __shared__ double lds[2 * W::N];
+    const uint32_t t = threadIdx.x;
+    typename W::Xchg xc{lds, 0};
+    double x[W::E], y[W::E];
+#pragma unroll
+    for (int m = 0; m < W::E; m++) {
+        x[m] = fp_from_u64(a[W::template index_of<0>(t, m)]);
+        y[m] = fp_from_u64(b[W::template index_of<0>(t, m)]);
+    }
+    W::forward(x, xc, t, tw_fwd);
+    W::forward(y, xc, t, tw_fwd);
+#pragma unroll
+    for (int m = 0; m < W::E; m++) x[m] = fp_mulmod(fp_mulmod(x[m], fp_center(y[m])), n_inv);
+    W::inverse(x, xc, t, tw_inv);
+#pragma unroll
+    for (int m = 0; m < W::E; m++) c[W::template index_of<0>(t, m)] = fp_to_u64(fp_canon(x[m]));
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int LOGN, int LL>
+__global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
+    using W = PolyNtt<LOGN, LL>;
+    constexpr int N = W::N, E = W::E, LANES = W::LANES;
+    __shared__ double lds[2 * 2 * N];             // [component][ping-pong][N]
+    const uint32_t comp = threadIdx.x >> LL;      // GLWE component owned by this thread: 0 = mask, 1 = body
+    const uint32_t t = threadIdx.x & (LANES - 1);
+    double *mine = lds + comp * 2 * N;
+    double *theirs = lds + (comp ^ 1u) * 2 * N;
+    typename W::Xchg xc{mine, 0};
+
+    const size_t f = blockIdx.x;
+    const size_t gate = f / a.gv.s_count;
+    const uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    const uint32_t *ms = a.ms + f * (a.n + 1);
+    const uint64_t *tv = a.tvs + (size_t)table * N;
+    const uint32_t rows = 2 * a.l;
+
+    // ACC = (0, X^{-b~} * TV), canonical; register m of lane t is coefficient t + LANES*m
+    double acc[E];
+    {
+        const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
+            const uint64_t v = tv[idx & (N - 1)];
+            acc[m] = comp ? fp_from_u64((idx & N) ? fq_neg(v) : v) : 0.0;
+        }
+    }
+
+    const uint32_t rshift = FQ_BITS - 1 - a.l * a.beta;
+    const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
+
+    for (uint32_t i = 0; i < a.n; i++) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(ms[i]);
+        if (r == 0) continue;   // X^0 * ACC - ACC = 0: nothing to add (uniform over the workgroup)
+
+        // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
+        uint32_t abar[E];
+        {
+            double *buf = xc.next();
+            if constexpr (LL == 6) W::sync();
+            W::template store_group<0>(buf, t, acc);
+            W::sync();
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
+                const double v = buf[W::phys(idx & (N - 1))];
+                const double d = fp_canon(((idx & N) ? -v : v) - acc[m]);      // (-2q, q) -> [0, q)
+                abar[m] = (uint32_t)(((fp_to_u64(d) >> rshift) + 1) >> 1);
+            }
+        }
+
+        // ---- digits, least significant level first; NTT; multiply-accumulate with the key row ---
+        double own[E], other[E];   // contributions to this component and to the partner's (lazy sums)
+#pragma unroll
+        for (int m = 0; m < E; m++) own[m] = other[m] = 0.0;
+        for (int lv = (int)a.l - 1; lv >= 0; lv--) {
+            double x[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const uint32_t dg = abar[m] & bmask;
+                const uint32_t carry = dg >= bhalf ? 1u : 0u;
+                abar[m] = (abar[m] >> a.beta) + carry;
+                x[m] = (double)((int)dg - (int)(carry << a.beta));   // balanced digit in [-B/2, B/2)
+            }
+            W::forward(x, xc, t, a.tw_fwd);
+            const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
+            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
+            const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+#pragma unroll
+            for (int m = 0; m < E; m += 2) {
+                const double2 ko = k_own[(m >> 1) * LANES + t];
+                const double2 kt = k_oth[(m >> 1) * LANES + t];
+                own[m] += fp_mulmod(x[m], ko.x);
+                own[m + 1] += fp_mulmod(x[m + 1], ko.y);
+                other[m] += fp_mulmod(x[m], kt.x);
+                other[m + 1] += fp_mulmod(x[m + 1], kt.y);
+            }
+        }
+
+        // ---- hand the partner its half of the external product (same ping-pong slot in both regions) ----
+        {
+            const uint32_t slot = xc.pp ? N : 0;
+            xc.pp ^= 1u;
+            if constexpr (LL == 6) __syncthreads();   // wave-private exchanges: the partner may still be inside its own
+#pragma unroll
+            for (int m = 0; m < E; m++) theirs[slot + m * LANES + t] = other[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; m++) own[m] += mine[slot + m * LANES + t];
+        }
+
+        // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
+        W::inverse(own, xc, t, a.tw_inv);
+#pragma unroll
+        for (int m = 0; m < E; m++) acc[m] = fp_canon(acc[m] + own[m]);
+    }
+
+    // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
+    uint64_t *out = gate_out(a.gv, f, a.ct_words);
+    if (comp == 0) {
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t j = t + (uint32_t)LANES * m;
+            const uint64_t v = fp_to_u64(acc[m]);
+            if (j == 0) out[0] = v;
+            else out[N - j] = fq_neg(v);
+        }
+    } else if (t == 0) {
+        out[N] = fq_add(fp_to_u64(acc[0]), a.post[table]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define FBS_FOR_EACH_SHAPE(X) X(8) X(9) X(10) X(11)
+
+template <int LOGN>
+static int upload_keys_t(fbs_ctx *ctx) {
+    constexpr int LL = lanes_log2_for(LOGN);
+    const fbs_params &p = ctx->p;
+    const uint32_t N = ctx->N;
+    const size_t polys = (size_t)p.n * ctx->rows * (p.k + 1);
+    uint64_t *d_src = nullptr;
+    FBS_HIP(ctx, hipMalloc(&d_src, polys * N * 8));
+    hipError_t e = hipMemcpyAsync(d_src, ctx->bsk.data(), polys * N * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const double n_inv = fq_centered(fq_inv(N));
+        unsigned grid = (unsigned)std::min<size_t>(polys, 4096);
+        hipLaunchKernelGGL((k_bsk_transform<LOGN, LL>), dim3(grid), dim3(1 << LL), 0, ctx->stream, d_src,
+                           reinterpret_cast<double *>(ctx->d_bsk_hat), reinterpret_cast<const double *>(ctx->d_tw_fwd), n_inv,
+                           polys);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_src);
+    if (e != hipSuccess) return set_error(ctx, FBS_E_DEVICE, std::string("bootstrapping-key transform: ") + hipGetErrorString(e));
+    return FBS_OK;
+}
+
+int dev_upload_keys(fbs_ctx *ctx) {
+    const fbs_params &p = ctx->p;
+    const uint32_t N = ctx->N;
+    std::vector<uint64_t> fwd, inv;
+    host_twiddles(p.log_n_poly, fwd, inv);
+    std::vector<double> fwd_c(N), inv_c(N);
+    for (uint32_t i = 0; i < N; i++) {
+        fwd_c[i] = fq_centered(fwd[i]);
+        inv_c[i] = fq_centered(inv[i]);
+    }
+    const size_t bsk_words = (size_t)p.n * ctx->rows * (p.k + 1) * N;
+    const size_t ksk_rows = (size_t)ctx->D * p.t_ksk;
+    if (!ctx->d_tw_fwd) {
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_bsk_hat, bsk_words * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_ksk, ksk_rows * ctx->ksk_stride * 8));
+    }
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_fwd, fwd_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_inv, inv_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FBS_HIP(ctx, hipMemsetAsync(ctx->d_ksk, 0, ksk_rows * ctx->ksk_stride * 8, ctx->stream));
+    FBS_HIP(ctx, hipMemcpy2DAsync(ctx->d_ksk, (size_t)ctx->ksk_stride * 8, ctx->ksk.data(), (size_t)(p.n + 1) * 8,
+                                  (size_t)(p.n + 1) * 8, ksk_rows, hipMemcpyHostToDevice, ctx->stream));
+    FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // fwd_c / inv_c are about to go out of scope
+    switch (p.log_n_poly) {
+#define X(L) case L: return upload_keys_t<L>(ctx);
+        FBS_FOR_EACH_SHAPE(X)
+#undef X
+    }
+    return set_error(ctx, FBS_E_INVALID, "unsupported N");
+}
+
+int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream) {
+    const fbs_params &p = ctx->p;
+    BrArgs a{};
+    a.gv = gv;
+    a.ms = d_ms;
+    a.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat);
+    a.tw_fwd = reinterpret_cast<const double *>(ctx->d_tw_fwd);
+    a.tw_inv = reinterpret_cast<const double *>(ctx->d_tw_inv);
+    a.tvs = tv->d_tvs;
+    a.post = tv->d_post;
+    a.n = p.n;
+    a.l = p.l_bsk;
+    a.beta = p.beta_bsk;
+    a.ct_words = ctx->D + 1;
+    const size_t count = (size_t)gv.n_gates * gv.s_count;
+    if (count == 0) return FBS_OK;
+    if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");
+    dim3 grid((unsigned)count);
+    hipEvent_t e0, e1;
+    prof_begin(ctx, 1, stream, &e0, &e1);
+    switch (p.log_n_poly) {
+#define X(L)                                                                                                           \
+    case L:                                                                                                            \
+        hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L)>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a);  \
+        break;
+        FBS_FOR_EACH_SHAPE(X)
+#undef X
+        default: return set_error(ctx, FBS_E_INVALID, "unsupported N");
+    }
+    prof_end(ctx, 1, stream, e0, e1);
+    FBS_HIP(ctx, hipGetLastError());
+    return FBS_OK;
+}
+
+int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream) {
+    const double n_inv = fq_centered(fq_inv(ctx->N));
+    const double *twf = reinterpret_cast<const double *>(ctx->d_tw_fwd), *twi = reinterpret_cast<const double *>(ctx->d_tw_inv);
+    switch (ctx->p.log_n_poly) {
+#define X(L)                                                                                                               \
+    case L:                                                                                                                \
+        hipLaunchKernelGGL((k_polymul<L, lanes_log2_for(L)>), dim3(1), dim3(1 << lanes_log2_for(L)), 0, stream, d_a, d_b, \
+                           d_c, twf, twi, n_inv);                                                                          \
+        break;
+        FBS_FOR_EACH_SHAPE(X)
+#undef X
+        default: return set_error(ctx, FBS_E_INVALID, "unsupported N");
+    }
+    FBS_HIP(ctx, hipGetLastError());
+    return FBS_OK;
+}
+
+}  // namespace fbs

@@ -58,6 +58,14 @@ static int to_device(fbs_ctx *ctx, fbs_prog *prog, const std::vector<T> &v, T **
     return FBS_OK;
 }
 
+// a LinearProd coefficient as the kernel wants it: centred residue, as the bit pattern of a double
+static uint64_t coef_bits(int64_t c) {
+    const double d = fq_centered(fq_from_i64(c));
+    uint64_t u;
+    std::memcpy(&u, &d, sizeof u);
+    return u;
+}
+
 static hipStream_t pick(fbs_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
 static int ensure_ms(fbs_ctx *ctx, size_t count) {
@@ -90,10 +98,10 @@ int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx 
     ctx->ksk_stride = ((p.n + 1 + 255) / 256) * 256;
     int rc = dev_supported(ctx.get());
     if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
-    ctx->delta_half = (uint64_t)(((unsigned __int128)GQ + 2ull * p.p_msg) / (4ull * p.p_msg));
+    ctx->delta_half = (uint64_t)(((unsigned __int128)FQ + 2ull * p.p_msg) / (4ull * p.p_msg));
     auto round_div = [](uint32_t e) {
         unsigned __int128 d = (unsigned __int128)1 << e;
-        return (uint64_t)(((unsigned __int128)GQ + d / 2) / d);
+        return (uint64_t)(((unsigned __int128)FQ + d / 2) / d);
     };
     for (uint32_t lv = 0; lv < p.l_bsk; lv++) ctx->g[lv] = round_div(p.beta_bsk * (lv + 1));
     for (uint32_t v = 0; v < p.t_ksk; v++) ctx->h[v] = round_div(p.gamma_ksk * (v + 1));
@@ -336,8 +344,8 @@ int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, c
     std::memcpy(stage.data() + n_out, term_off, (size_t)(n_out + 1) * 4);
     if (n_terms) std::memcpy(stage.data() + 2 * (size_t)n_out + 1, srcs, (size_t)n_terms * 4);
     uint64_t *f = reinterpret_cast<uint64_t *>(stage.data() + u32_words);
-    for (uint32_t i = 0; i < n_terms; i++) f[i] = gl_from_i64(coefs[i]);
-    for (uint32_t g = 0; g < n_out; g++) f[n_terms + g] = gl_mul(gl_from_i64(consts[g]), 2 * ctx->delta_half);
+    for (uint32_t i = 0; i < n_terms; i++) f[i] = coef_bits(coefs[i]);
+    for (uint32_t g = 0; g < n_out; g++) f[n_terms + g] = fq_mul(fq_from_i64(consts[g]), 2 * ctx->delta_half);
     FBS_HIP(ctx, hipMemcpyAsync(ctx->d_idx, stage.data(), total * 4, hipMemcpyHostToDevice, s));
     FBS_HIP(ctx, hipStreamSynchronize(s));   // `stage` is pageable host memory going out of scope
     const uint32_t *d_dst = ctx->d_idx, *d_off = ctx->d_idx + n_out, *d_srcs = ctx->d_idx + 2 * (size_t)n_out + 1;
@@ -454,10 +462,10 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *t
             h.dst.push_back(w);
             for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
                 h.srcs.push_back(d->term_src[t]);
-                h.coefs.push_back(gl_from_i64(d->term_coef[t]));
+                h.coefs.push_back(coef_bits(d->term_coef[t]));
             }
             h.off.push_back((uint32_t)h.srcs.size());
-            h.consts.push_back(gl_mul(gl_from_i64(d->const_coef[i]), 2 * ctx->delta_half));
+            h.consts.push_back(fq_mul(fq_from_i64(d->const_coef[i]), 2 * ctx->delta_half));
         } else {
             BootHost &b = bh[level[w] - 1];
             b.src.push_back(d->arg0[i]);
@@ -574,7 +582,7 @@ int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uin
             if (w >= 0) {
                 FBS_HIP(ctx, hipMemcpyAsync(dst, prog->d_wires + (size_t)w * TW * ctw, tc * ctw * 8, hipMemcpyDeviceToHost, s));
             } else {
-                const uint64_t body = gl_mul(gl_from_i64(-1 - w), 2 * ctx->delta_half);   // trivial ciphertext of the constant
+                const uint64_t body = fq_mul(fq_from_i64(-1 - w), 2 * ctx->delta_half);   // trivial ciphertext of the constant
                 for (size_t q = 0; q < tc; q++) {
                     std::memset(dst + q * ctw, 0, ctx->D * 8);
                     dst[q * ctw + ctx->D] = body;

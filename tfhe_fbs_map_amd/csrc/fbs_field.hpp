@@ -1,86 +1,90 @@
-// Arithmetic in Z_q, q = 2^64 - 2^32 + 1 ("Goldilocks"), for host and gfx950 device code.
+// Arithmetic in Z_q, q = 2^46 - 62*2^13 + 1 = 0x3FFFFFF84001 (prime, 2^14 | q-1), the ciphertext modulus AND the
+// NTT modulus of libfbsexec.  Residues travel in 64-bit words.
 //
-// q is the ciphertext modulus AND the NTT modulus: 2^64 = 2^32 - 1 and 2^96 = -1 (mod q), so a
-// 128-bit product folds back to 64 bits with shifts and adds only, and the negacyclic NTT of any
-// power-of-two size up to 2^31 exists.  CDNA4 has no 64-bit multiplier: a product is four
-// v_mad_u64_u32; everything else is 32-bit adds with carry.
-//
-// Value discipline in the kernels:
-//   * "canonical" = in [0, q).  Everything stored to HBM is canonical.
-//   * "loose"     = any 64-bit word (a representative, possibly >= q).
-//   add_cl(a, b), sub_lc(a, b): exact when the operand marked c is canonical.
+// Why 46 bits.  gfx950 has no 64-bit integer multiplier: a 64x64 modular product costs ~25 VALU instructions
+// (4 v_mad_u64_u32 + carry chains), and the blind rotation is nothing but such products.  The FP64 pipe runs
+// v_fma_f64 at the same issue rate as any 64-bit integer instruction and an FMA is an EXACT 53-bit integer
+// multiply-add.  With q < 2^46:
+//     h = x*w (rounded), l = fma(x, w, -h) (exact remainder), qh = rint(h / q), r = fma(-qh, q, h) + l
+// is the exact residue of x*w in (-0.75 q, 0.75 q) for |x| < 2^50, 6 instructions, no carries, no compares.
+// Values are kept as integer-valued doubles in a signed, LAZY range: a butterfly is the product plus one add and
+// one sub, and ten Cooley-Tukey stages grow |x| by at most 0.75 q each (7.5 q < 2^50) -- no range fix-ups at all.
+// Measured on MI355X (tools/bf_bench.hip): 3.48e12 butterflies/s against 1.07e12 for a u64 Goldilocks butterfly.
+// Everything that leaves the kernels (ciphertexts, key material in standard layout) is a canonical integer in
+// [0, q) in a uint64 word, so the CPU oracle -- which computes the same residues with integer arithmetic -- is
+// compared word for word.
 #pragma once
 #include <stdint.h>
 
 #if defined(__HIPCC__)
 #define FBS_HD __host__ __device__ __forceinline__
+#define FBS_D __device__ __forceinline__
 #else
 #define FBS_HD inline
 #endif
 
 namespace fbs {
 
-constexpr uint64_t GQ = 0xFFFFFFFF00000001ull;
-constexpr uint64_t GEPS = 0xFFFFFFFFull;  // 2^64 mod q
+constexpr uint64_t FQ = 0x3FFFFFF84001ull;
+constexpr int FQ_BITS = 46;
+constexpr uint64_t FQ_GENERATOR = 7;   // generates Z_q^*: q - 1 = 2^14 * 3^2 * 5 * 95443717
 
-// (hi:lo) < 2^128 -> loose representative.
-FBS_HD uint64_t gl_reduce128(uint64_t lo, uint64_t hi) {
-    uint32_t h0 = (uint32_t)hi, h1 = (uint32_t)(hi >> 32);
-    uint64_t t;
-    bool borrow = __builtin_sub_overflow(lo, (uint64_t)h1, &t);  // lo - h1*2^96  (2^96 = -1)
-    t -= borrow ? GEPS : 0;                                      // wrapped below 0: +q == -eps mod 2^64
-    uint64_t u = ((uint64_t)h0 << 32) - h0;                      // h0 * 2^64 = h0 * eps
-    uint64_t r;
-    bool carry = __builtin_add_overflow(t, u, &r);
-    r += carry ? GEPS : 0;
-    return r;
+// ---- integer arithmetic on canonical residues (host code, and the non-hot kernels) ------------------------
+FBS_HD uint64_t fq_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    return s >= FQ ? s - FQ : s;
 }
-
-FBS_HD uint64_t gl_canon(uint64_t r) { return r >= GQ ? r - GQ : r; }
-
-FBS_HD uint64_t gl_mul_loose(uint64_t a, uint64_t b) {
-    unsigned __int128 p = (unsigned __int128)a * b;
-    return gl_reduce128((uint64_t)p, (uint64_t)(p >> 64));
+FBS_HD uint64_t fq_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + FQ - b; }
+FBS_HD uint64_t fq_neg(uint64_t a) { return a ? FQ - a : 0; }
+FBS_HD uint64_t fq_mul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % FQ); }
+FBS_HD uint64_t fq_from_i64(int64_t v) {
+    if (v >= 0) return (uint64_t)v % FQ;
+    uint64_t m = (0 - (uint64_t)v) % FQ;
+    return m ? FQ - m : 0;
 }
-FBS_HD uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_canon(gl_mul_loose(a, b)); }
-
-// a loose, b canonical -> loose
-FBS_HD uint64_t gl_add_lc(uint64_t a, uint64_t b) {
-    uint64_t s;
-    bool c = __builtin_add_overflow(a, b, &s);
-    s += c ? GEPS : 0;
-    return s;
+// uniform residue from a 64-bit random word: top FQ_BITS bits, folded once (bias 2^-27)
+FBS_HD uint64_t fq_fold(uint64_t r) {
+    r >>= 64 - FQ_BITS;
+    return r >= FQ ? r - FQ : r;
 }
-// a loose, b canonical -> loose
-FBS_HD uint64_t gl_sub_lc(uint64_t a, uint64_t b) {
-    uint64_t d;
-    bool c = __builtin_sub_overflow(a, b, &d);
-    d -= c ? GEPS : 0;
-    return d;
-}
-// both canonical -> canonical
-FBS_HD uint64_t gl_add(uint64_t a, uint64_t b) { return gl_canon(gl_add_lc(a, b)); }
-FBS_HD uint64_t gl_sub(uint64_t a, uint64_t b) {
-    uint64_t d = a - b;
-    return a < b ? d + GQ : d;
-}
-FBS_HD uint64_t gl_neg(uint64_t a) { return a ? GQ - a : 0; }
-
-FBS_HD uint64_t gl_from_i64(int64_t v) {
-    if (v >= 0) return (uint64_t)v % GQ;
-    uint64_t m = (0 - (uint64_t)v) % GQ;
-    return m ? GQ - m : 0;
-}
-
-inline uint64_t gl_pow(uint64_t a, uint64_t e) {
+inline uint64_t fq_pow(uint64_t a, uint64_t e) {
     uint64_t r = 1;
     while (e) {
-        if (e & 1) r = gl_mul(r, a);
-        a = gl_mul(a, a);
+        if (e & 1) r = fq_mul(r, a);
+        a = fq_mul(a, a);
         e >>= 1;
     }
     return r;
 }
-inline uint64_t gl_inv(uint64_t a) { return gl_pow(a, GQ - 2); }
+inline uint64_t fq_inv(uint64_t a) { return fq_pow(a, FQ - 2); }
+// centred representative in (-q/2, q/2] as a double (how twiddles and key polynomials are stored for the kernels)
+inline double fq_centered(uint64_t a) { return a > FQ / 2 ? -(double)(FQ - a) : (double)a; }
+
+// ---- device-side exact FP64 arithmetic ---------------------------------------------------------------------
+#if defined(__HIPCC__)
+constexpr double FP_Q = 70368743669761.0;            // q, exactly representable
+constexpr double FP_QINV = 1.0 / 70368743669761.0;   // correctly rounded at compile time
+constexpr double FP_MAGIC = 4503599627370496.0;      // 2^52: x + 2^52 exposes the integer x in the mantissa
+
+// exact residue of x*w in (-0.75q, 0.75q); needs |x| < 2^50 and |w| <= q (twiddles/keys are stored centred)
+FBS_D double fp_mulmod(double x, double w) {
+    const double h = x * w;
+    const double l = __builtin_fma(x, w, -h);
+    const double qh = __builtin_rint(h * FP_QINV);
+    return __builtin_fma(-qh, FP_Q, h) + l;
+}
+// representative in [-q/2, q/2] (up to the rounding of x/q); needs |x| < 2^52
+FBS_D double fp_center(double x) { return __builtin_fma(-__builtin_rint(x * FP_QINV), FP_Q, x); }
+// canonical representative in [0, q); needs |x| < 2^52
+FBS_D double fp_canon(double x) {
+    const double c = fp_center(x);
+    return c < 0.0 ? c + FP_Q : c;
+}
+// integer-valued double in [0, 2^52) <-> uint64
+FBS_D uint64_t fp_to_u64(double x) { return (uint64_t)__double_as_longlong(x + FP_MAGIC) & 0x000FFFFFFFFFFFFFull; }
+FBS_D double fp_from_u64(uint64_t v) {   // v < 2^52
+    return __longlong_as_double((long long)(v | 0x4330000000000000ull)) - FP_MAGIC;
+}
+#endif
 
 }  // namespace fbs

@@ -49,7 +49,7 @@ struct ChaCha {
             out[i] = (uint64_t)(x[2 * i] + in[2 * i]) | ((uint64_t)(x[2 * i + 1] + in[2 * i + 1]) << 32);
     }
 };
-inline uint64_t fold(uint64_t r) { return r >= GQ ? r - GQ : r; }   // 2^-32 bias, documented
+inline uint64_t fold(uint64_t r) { return r >= FQ ? r - FQ : r; }   // 2^-32 bias, documented
 }  // namespace
 
 void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count) {
@@ -124,20 +124,20 @@ void host_keygen(fbs_ctx *ctx) {
             uint64_t *row = ctx->bsk.data() + r * row_words;
             uint64_t *body = row + (size_t)k * N;
             for (uint32_t j = 0; j < N; j++)
-                body[j] = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_BSK_NOISE, r), j, p.sigma_glwe));
+                body[j] = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_BSK_NOISE, r), j, p.sigma_glwe));
             for (uint32_t c = 0; c < k; c++) {
                 uint64_t *a = row + (size_t)c * N;
                 rand_words(ctx->seed, stream_id(DOM_BSK_MASK, r), (uint64_t)c * N, a, N);
-                for (uint32_t j = 0; j < N; j++) a[j] = fold(a[j]);
+                for (uint32_t j = 0; j < N; j++) a[j] = fq_fold(a[j]);
                 std::fill(prod.begin(), prod.end(), 0);
                 for (uint32_t sh : support[c]) {
                     // prod += X^sh * a
-                    for (uint32_t j = 0; j < N - sh; j++) prod[j + sh] = gl_add(prod[j + sh], a[j]);
-                    for (uint32_t j = N - sh; j < N; j++) prod[j + sh - N] = gl_sub(prod[j + sh - N], a[j]);
+                    for (uint32_t j = 0; j < N - sh; j++) prod[j + sh] = fq_add(prod[j + sh], a[j]);
+                    for (uint32_t j = N - sh; j < N; j++) prod[j + sh - N] = fq_sub(prod[j + sh - N], a[j]);
                 }
-                for (uint32_t j = 0; j < N; j++) body[j] = gl_add(body[j], prod[j]);
+                for (uint32_t j = 0; j < N; j++) body[j] = fq_add(body[j], prod[j]);
             }
-            if (ctx->sk_lwe[i]) row[(size_t)comp * N] = gl_add(row[(size_t)comp * N], ctx->g[lv]);
+            if (ctx->sk_lwe[i]) row[(size_t)comp * N] = fq_add(row[(size_t)comp * N], ctx->g[lv]);
         }
     });
 
@@ -147,12 +147,12 @@ void host_keygen(fbs_ctx *ctx) {
             uint32_t j = (uint32_t)(r / t), v = (uint32_t)(r % t);
             uint64_t *row = ctx->ksk.data() + r * (n + 1);
             rand_words(ctx->seed, stream_id(DOM_KSK_MASK, r), 0, row, n);
-            uint64_t b = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_KSK_NOISE, r), 0, p.sigma_lwe));
+            uint64_t b = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_KSK_NOISE, r), 0, p.sigma_lwe));
             for (uint32_t i = 0; i < n; i++) {
-                row[i] = fold(row[i]);
-                if (ctx->sk_lwe[i]) b = gl_add(b, row[i]);
+                row[i] = fq_fold(row[i]);
+                if (ctx->sk_lwe[i]) b = fq_add(b, row[i]);
             }
-            if (ctx->sk_glwe[j]) b = gl_add(b, ctx->h[v]);
+            if (ctx->sk_glwe[j]) b = fq_add(b, ctx->h[v]);
             row[n] = b;
         }
     });
@@ -168,12 +168,12 @@ void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_
         for (size_t i = a; i < b; i++) {
             uint64_t *ct = cts + i * (D + 1);
             rand_words(ctx->seed, stream_id(DOM_ENC_MASK, nonce0 + i), 0, ct, D);
-            uint64_t body = gl_from_i64(noise_sample(ctx->seed, stream_id(DOM_ENC_NOISE, nonce0 + i), 0, ctx->p.sigma_glwe));
+            uint64_t body = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_ENC_NOISE, nonce0 + i), 0, ctx->p.sigma_glwe));
             for (uint32_t j = 0; j < D; j++) {
-                ct[j] = fold(ct[j]);
-                if (ctx->sk_glwe[j]) body = gl_add(body, ct[j]);
+                ct[j] = fq_fold(ct[j]);
+                if (ctx->sk_glwe[j]) body = fq_add(body, ct[j]);
             }
-            ct[D] = gl_add(body, gl_mul(gl_from_i64(msgs[i]), delta));
+            ct[D] = fq_add(body, fq_mul(fq_from_i64(msgs[i]), delta));
         }
     });
 }
@@ -186,9 +186,9 @@ void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t
             const uint64_t *ct = cts + i * (D + 1);
             uint64_t phase = ct[D];
             for (uint32_t j = 0; j < D; j++)
-                if (ctx->sk_glwe[j]) phase = gl_sub(phase, ct[j]);
-            unsigned __int128 v = (unsigned __int128)phase * two_p + GQ / 2;
-            msgs[i] = (int64_t)((uint64_t)(v / GQ) % two_p);
+                if (ctx->sk_glwe[j]) phase = fq_sub(phase, ct[j]);
+            unsigned __int128 v = (unsigned __int128)phase * two_p + FQ / 2;
+            msgs[i] = (int64_t)((uint64_t)(v / FQ) % two_p);
         }
     });
 }
@@ -211,13 +211,13 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
     std::vector<uint64_t> enc(p);
     for (uint32_t x = 0; x < p; x++) {
         int64_t f = x < len ? table[x] : 0;   // unreachable slots
-        enc[x] = gl_mul(gl_from_i64(2 * f - c), ctx->delta_half);
+        enc[x] = fq_mul(fq_from_i64(2 * f - c), ctx->delta_half);
     }
     for (uint32_t j = 0; j < N; j++) {
         uint64_t x = ((uint64_t)j * 2 * p + N) / (2ull * N);   // nearest multiple of N/p
-        tv[j] = x < p ? enc[x] : gl_neg(enc[0]);               // the half box below X^N wraps to -f(0)
+        tv[j] = x < p ? enc[x] : fq_neg(enc[0]);               // the half box below X^N wraps to -f(0)
     }
-    *post_add = gl_mul(gl_from_i64(c), ctx->delta_half);
+    *post_add = fq_mul(fq_from_i64(c), ctx->delta_half);
     return FBS_OK;
 }
 
@@ -228,26 +228,26 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
 // ---------------------------------------------------------------------------------------------
 void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv) {
     const uint32_t N = 1u << log_n;
-    uint64_t psi = gl_pow(7, (GQ - 1) / (2ull * N));
+    uint64_t psi = fq_pow(7, (FQ - 1) / (2ull * N));
     if (N >= 32) {
-        uint64_t hroot = gl_pow(psi, N / 32);   // order 64
+        uint64_t hroot = fq_pow(psi, N / 32);   // order 64
         uint64_t acc = hroot;
         for (uint32_t f = 1; f < 64; f += 2) {
             if (acc == 8) {
-                psi = gl_pow(psi, f);
+                psi = fq_pow(psi, f);
                 break;
             }
-            acc = gl_mul(acc, gl_mul(hroot, hroot));
+            acc = fq_mul(acc, fq_mul(hroot, hroot));
         }
     }
-    const uint64_t psi_inv = gl_inv(psi);
+    const uint64_t psi_inv = fq_inv(psi);
     fwd.assign(N, 1);
     inv.assign(N, 1);
     for (uint32_t i = 1; i < N; i++) {
         uint32_t r = 0;
         for (uint32_t b = 0; b < log_n; b++) r |= ((i >> b) & 1u) << (log_n - 1 - b);
-        fwd[i] = gl_pow(psi, r);
-        inv[i] = gl_pow(psi_inv, r);
+        fwd[i] = fq_pow(psi, r);
+        inv[i] = fq_pow(psi_inv, r);
     }
 }
 

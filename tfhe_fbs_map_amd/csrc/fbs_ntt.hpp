@@ -1,0 +1,183 @@
+// Negacyclic NTT mod q (fbs_field.hpp) of one polynomial spread over LANES = 2^LL lanes (one or more wavefronts),
+// gfx950, exact FP64 arithmetic on integer-valued doubles.
+//
+// Each lane holds E = N/LANES coefficients in VGPRs.  A transform is a chain of "groups": log2(E) radix-2
+// butterfly stages on registers, then an exchange through LDS that brings the next group of index bits into the
+// lane.  With LANES = 64 the exchange is private to a wave (no barrier); with more lanes the waves of a polynomial
+// meet at one s_barrier per exchange.  Exchanges ping-pong between two N-word buffers, so one barrier per
+// exchange is enough: a buffer is rewritten only after every wave has passed the barrier that follows its last
+// read of it.
+//
+// Forward = Cooley-Tukey with the twist folded into the twiddles (tw[i] = psi^bitrev(i)), natural order in,
+// bit-reversed evaluation order out.  Lazy ranges: inputs |x| <= q, every stage adds a product below 0.75 q, so
+// after LOGN <= 11 stages |x| < 9.3 q < 2^50 -- the bound fp_mulmod needs -- without a single range fix-up.
+// Inverse = Gentleman-Sande with tw[i] = psi^-bitrev(i); sums double per stage, so each group starts by centring
+// its registers (|x| <= q/2) and may run at most 4 stages (8 q before the last product).  The 1/N is folded into
+// the bootstrapping key.  All twiddles are stored centred, as doubles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fbs_field.hpp"
+
+namespace fbs {
+
+template <int LOGN, int LL>
+struct PolyNtt {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LANES = 1 << LL;
+    static constexpr int E = N / LANES;
+    static constexpr int LOGE = LOGN - LL;
+    static constexpr int GROUPS = (LOGN + LOGE - 1) / LOGE;
+    static_assert(LL >= 6 && LOGE >= 2 && LOGE <= 4 && LOGN <= 11, "unsupported shape (range analysis assumes <= 4 stages per group)");
+
+    // lowest index bit held inside the lane during group g
+    __host__ __device__ static constexpr int lo_of(int g) { return (LOGN - (g + 1) * LOGE) > 0 ? (LOGN - (g + 1) * LOGE) : 0; }
+
+    // LDS word of coefficient j: index bits 4.. folded (XOR) into the bank-selecting bits 0..4
+    __device__ static __forceinline__ uint32_t phys(uint32_t j) { return j ^ ((j >> 4) & 31u); }
+
+    // coefficient index of register m of lane t during group G
+    template <int G>
+    __device__ static __forceinline__ uint32_t index_of(uint32_t t, int m) {
+        constexpr int lo = lo_of(G);
+        return ((t >> lo) << (lo + LOGE)) | ((uint32_t)m << lo) | (t & ((1u << lo) - 1u));
+    }
+
+    template <int G>
+    __device__ static __forceinline__ void store_group(double *buf, uint32_t t, const double (&x)[E]) {
+        const uint32_t base = phys(index_of<G>(t, 0));
+#pragma unroll
+        for (int m = 0; m < E; m++) buf[base ^ phys(index_of<G>(0, m))] = x[m];   // phys is XOR-linear
+    }
+    template <int G>
+    __device__ static __forceinline__ void load_group(const double *buf, uint32_t t, double (&x)[E]) {
+        const uint32_t base = phys(index_of<G>(t, 0));
+#pragma unroll
+        for (int m = 0; m < E; m++) x[m] = buf[base ^ phys(index_of<G>(0, m))];
+    }
+
+    // make LDS writes of the polynomial's lanes visible to its lanes
+    __device__ static __forceinline__ void sync() {
+        if constexpr (LL == 6) {
+            // one wave: LDS operations complete in issue order; only the compiler must be held back
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    }
+
+    // Ping-pong exchange state: `bufs` = two N-word buffers of this polynomial, `pp` = which is next.
+    struct Xchg {
+        double *bufs;
+        uint32_t pp;
+        __device__ __forceinline__ double *next() {
+            double *b = bufs + (pp ? N : 0);
+            pp ^= 1u;
+            return b;
+        }
+    };
+
+    // Cooley-Tukey stages of group G on registers
+    template <int G>
+    __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const double *__restrict__ tw) {
+        constexpr int lo = lo_of(G);
+        constexpr int s_begin = G * LOGE;
+        constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
+        const uint32_t hi_part = t >> lo;
+#pragma unroll
+        for (int s = s_begin; s < s_end; s++) {
+            const int bit = LOGN - 1 - s - lo;   // register-index bit paired by this stage
+            const int hm = 1 << bit;
+            const int sh = lo + LOGE - LOGN + s;  // how far the lane's high part reaches into the block id
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                if (m & hm) continue;
+                const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
+                const double w = tw[(1u << s) + blk];
+                const double u = x[m];
+                const double v = fp_mulmod(x[m + hm], w);
+                x[m] = u + v;
+                x[m + hm] = u - v;
+            }
+        }
+    }
+    // Gentleman-Sande stages of group G, last stage first
+    template <int G>
+    __device__ static __forceinline__ void inv_group(double (&x)[E], uint32_t t, const double *__restrict__ tw) {
+        constexpr int lo = lo_of(G);
+        constexpr int s_begin = G * LOGE;
+        constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
+        const uint32_t hi_part = t >> lo;
+#pragma unroll
+        for (int m = 0; m < E; m++) x[m] = fp_center(x[m]);
+#pragma unroll
+        for (int s = s_end - 1; s >= s_begin; s--) {
+            const int bit = LOGN - 1 - s - lo;
+            const int hm = 1 << bit;
+            const int sh = lo + LOGE - LOGN + s;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                if (m & hm) continue;
+                const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
+                const double w = tw[(1u << s) + blk];
+                const double u = x[m], v = x[m + hm];
+                x[m] = u + v;
+                x[m + hm] = fp_mulmod(u - v, w);
+            }
+        }
+    }
+
+    template <int G>
+    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+        fwd_group<G>(x, t, tw);
+        if constexpr (G + 1 < GROUPS) {
+            double *buf = xc.next();
+            if constexpr (LL == 6) sync();
+            store_group<G>(buf, t, x);
+            sync();
+            load_group<G + 1>(buf, t, x);
+            fwd_from<G + 1>(x, xc, t, tw);
+        }
+    }
+    template <int G>
+    __device__ static __forceinline__ void inv_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+        inv_group<G>(x, t, tw);
+        if constexpr (G > 0) {
+            double *buf = xc.next();
+            if constexpr (LL == 6) sync();
+            store_group<G>(buf, t, x);
+            sync();
+            load_group<G - 1>(buf, t, x);
+            inv_from<G - 1>(x, xc, t, tw);
+        }
+    }
+
+    // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
+    // (last-group layout, |x| < 9.3 q)
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+        fwd_from<0>(x, xc, t, tw);
+    }
+    // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q)
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+        inv_from<GROUPS - 1>(x, xc, t, tw);
+    }
+
+    // Key storage: the evaluation held in register m of lane t after forward() sits at word
+    // ((m/2)*LANES + t)*2 + (m&1) of its polynomial, so the lanes read a polynomial with E/2 fully
+    // coalesced 16-byte loads.
+    __host__ __device__ static constexpr uint32_t key_word(uint32_t t, int m) {
+        return (((uint32_t)(m >> 1) * LANES + t) << 1) | (uint32_t)(m & 1);
+    }
+};
+
+// lanes per polynomial for each supported size
+#ifndef FBS_COEFS_PER_LANE_LOG2
+#define FBS_COEFS_PER_LANE_LOG2 4
+#endif
+__host__ __device__ constexpr int lanes_log2_for(int log_n) {
+    return log_n - FBS_COEFS_PER_LANE_LOG2 < 6 ? 6 : log_n - FBS_COEFS_PER_LANE_LOG2;
+}
+
+}  // namespace fbs

@@ -7,7 +7,7 @@ not available here.  This module is the stand-in: the BASELINE.md set P1024 and 
 plus textbook CGGI variance formulas so a caller can see how many standard deviations of margin a
 (parameter set, p, norm2) combination has.  All variances are relative to q^2 (torus units).
 
-The default noise (sigma = 2^24 on a 2^64 modulus, i.e. 2^-40 relative) is REDUCED NOISE: it makes
+The default noise (sigma = 2^6 on the 46-bit modulus, i.e. 2^-40 relative) is REDUCED NOISE: it makes
 N=1024 correct for p=15 with generous margin but is far below what 128-bit security needs at these
 dimensions (~2^-25 at N=1024, which would not leave room for p=15).  Throughput does not depend on it.
 """
@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import math
 
-from ._native import Params
+from ._native import MODULUS, Params
 
 P1024 = Params()                                            # n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2
 P2048 = Params(n=630, log_n_poly=11, l_bsk=3, beta_bsk=7)   # p = 31 needs the wider accumulator
@@ -31,7 +31,7 @@ def params_for(p: int, norm2: int | None = None) -> Params:
 
 def variances(prm: Params):
     """(blind-rotate output, key switch, modulus switch) variances in torus units."""
-    q = 2.0 ** 64
+    q = float(MODULUS)
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
     B, b2 = 2.0 ** prm.beta_bsk, 2.0 ** prm.gamma_ksk
     s_glwe, s_lwe = prm.sigma_glwe / q, prm.sigma_lwe / q

@@ -11,7 +11,7 @@ def check(params, B, tables, seed=1, label=""):
     print(label, ctx.device_info, "keygen %.2fs" % (time.time() - t0), flush=True)
     rng = np.random.default_rng(42)
     N = params.N
-    a = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64); b = rng.integers(0, nat.GOLDILOCKS, N, dtype=np.uint64)
+    a = rng.integers(0, nat.MODULUS, N, dtype=np.uint64); b = rng.integers(0, nat.MODULUS, N, dtype=np.uint64)
     c = ctx.debug_polymul(a, b)
     print(" polymul == oracle ntt:", np.array_equal(c, orc.polymul_ntt(a, b)), flush=True)
     o = orc.Oracle(params, seed=seed)
@@ -33,7 +33,7 @@ def check(params, B, tables, seed=1, label=""):
     return ctx, tv
 
 rng = np.random.default_rng(3)
-toy = nat.Params(n=16, log_n_poly=10, p_msg=7, sigma_lwe=1 << 20, sigma_glwe=1 << 20)
+toy = nat.Params(n=16, log_n_poly=10, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 8)
 check(toy, 8, [[0,1,1,0,1,0,0], [0,1,2,3,2,1,0], [0,1,1,0,1,0,0,1,0,0,1,0,1,1]], label="toy N=1024")
 for logn in (8, 9, 11):
     check(toy.replace(log_n_poly=logn, n=12), 4, [[0,1,1,0,1,0,0]], label="toy N=%d" % (1 << logn))

@@ -1,0 +1,16 @@
+#!/bin/bash
+# PMC counters of the blind-rotation kernel for the library in $FBS_LIB (default: the product build)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/pmc_tmp
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_tmp/$(echo $c | cut -c1-12 | tr " " _) -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
+done
+python3 - <<PY
+import glob, csv, collections
+for f in sorted(glob.glob("gpurun_out/pmc_tmp/*/*/*counter_collection.csv")):
+    acc=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "blind_rotate" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k,v in acc.items(): print("%-24s %.4g" % (k, sum(v)/len(v)))
+PY
