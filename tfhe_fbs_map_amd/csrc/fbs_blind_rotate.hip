@@ -20,6 +20,10 @@
 
 namespace fbs {
 
+#ifndef FBS_BR_PREFETCH_KEYS
+#define FBS_BR_PREFETCH_KEYS 0
+#endif
+
 struct BrArgs {
     GateView gv;
     const uint32_t *ms;      // [count][n+1], values in [0, 2N)
@@ -104,8 +108,10 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
     const uint32_t rshift = FQ_BITS - 1 - a.l * a.beta;
     const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
 
+    uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
     for (uint32_t i = 0; i < a.n; i++) {
-        const uint32_t r = __builtin_amdgcn_readfirstlane(ms[i]);
+        const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
+        r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
         if (r == 0) continue;   // X^0 * ACC - ACC = 0: nothing to add (uniform over the workgroup)
 
         // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
@@ -137,19 +143,42 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
                 abar[m] = (abar[m] >> a.beta) + carry;
                 x[m] = (double)((int)dg - (int)(carry << a.beta));   // balanced digit in [-B/2, B/2)
             }
-            W::forward(x, xc, t, a.tw_fwd);
             const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
             const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+#if FBS_BR_PREFETCH_KEYS
+            // issue the key-row loads before the transform: they land while the butterflies run
+            double2 ko[E / 2];
+#pragma unroll
+            for (int m = 0; m < E / 2; m++) ko[m] = k_own[m * LANES + t];
+            W::forward(x, xc, t, a.tw_fwd);
 #pragma unroll
             for (int m = 0; m < E; m += 2) {
+                own[m] += fp_mulmod(x[m], ko[m >> 1].x);
+                own[m + 1] += fp_mulmod(x[m + 1], ko[m >> 1].y);
+            }
+#pragma unroll
+            for (int m = 0; m < E; m += 2) {
+                const double2 kt = k_oth[(m >> 1) * LANES + t];
+                other[m] += fp_mulmod(x[m], kt.x);
+                other[m + 1] += fp_mulmod(x[m + 1], kt.y);
+            }
+#else
+            W::forward(x, xc, t, a.tw_fwd);
+#pragma unroll
+            for (int m = 0; m < E; m += 2) {
+#if FBS_EXP_NOKEYLOAD   /* timing experiment only: wrong results */
+                const double2 ko = {1234567.0 + m, 7654321.0 + t}, kt = {2345671.0 + m, 6543217.0 + t};
+#else
                 const double2 ko = k_own[(m >> 1) * LANES + t];
                 const double2 kt = k_oth[(m >> 1) * LANES + t];
+#endif
                 own[m] += fp_mulmod(x[m], ko.x);
                 own[m + 1] += fp_mulmod(x[m + 1], ko.y);
                 other[m] += fp_mulmod(x[m], kt.x);
                 other[m + 1] += fp_mulmod(x[m + 1], kt.y);
             }
+#endif
         }
 
         // ---- hand the partner its half of the external product (same ping-pong slot in both regions) ----

@@ -42,13 +42,16 @@ __device__ __forceinline__ uint32_t ks_finish(uint64_t acc, uint64_t body, uint3
 template <int FB>
 __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     extern __shared__ uint32_t abar[];   // [FB][D]
+    __shared__ const uint64_t *ct_ptr[FB];
     const size_t f0 = (size_t)blockIdx.x * FB;
+    if (threadIdx.x < FB) ct_ptr[threadIdx.x] = f0 + threadIdx.x < a.count ? gate_in(a.gv, f0 + threadIdx.x, a.ct_words) : nullptr;
+    __syncthreads();
     const uint32_t col = blockIdx.y * 256u + threadIdx.x;
     const uint32_t tg = a.t * a.gamma;
 
     for (uint32_t idx = threadIdx.x; idx < FB * a.D; idx += 256) {
         const uint32_t f = idx / a.D, j = idx % a.D;
-        abar[idx] = f0 + f < a.count ? ks_round(gate_in(a.gv, f0 + f, a.ct_words)[j], tg) : 0u;
+        abar[idx] = ct_ptr[f] ? ks_round(ct_ptr[f][j], tg) : 0u;
     }
     __syncthreads();
 
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
 #pragma unroll
     for (int f = 0; f < FB; f++) {
         if (f0 + f >= a.count) break;
-        const uint64_t body = col == a.n ? gate_in(a.gv, f0 + f, a.ct_words)[a.D] : 0;
+        const uint64_t body = col == a.n ? ct_ptr[f][a.D] : 0;
         a.ms[(f0 + f) * (a.n + 1) + col] = ks_finish(acc[f], body, a.log2_2n);
     }
 }
@@ -86,8 +89,9 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
 // the LDS read (along the ciphertexts) are contiguous.
 template <int COLS>
 __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
-    constexpr int JT = 32;                       // mask words per wave per staging round
+    constexpr int JT = 16;                       // mask words per wave per staging round (16 KB of LDS: 8 workgroups/CU)
     __shared__ uint32_t tile[4 * JT * 64];       // [slice][j in tile][ciphertext]; reused for the final reduction
+    __shared__ const uint64_t *ct_ptr[64];       // row base of the 64 ciphertexts (the slot lookup costs a 64-bit division)
     static_assert(4 * JT * 64 >= 3 * COLS * 2 * 64, "reduction scratch must fit in the staging tile");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
     uint64_t acc[COLS];
 #pragma unroll
     for (int c = 0; c < COLS; c++) acc[c] = 0;
+    if (threadIdx.x < 64) ct_ptr[threadIdx.x] = f < a.count ? gate_in(a.gv, f, a.ct_words) : nullptr;
 
     for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
         __syncthreads();
@@ -109,19 +114,40 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
             const uint32_t jj = idx % JT, q = (idx / JT) % 64, sl = idx / (JT * 64);
             const uint32_t j = sl * slice_len + r0 + jj;
             uint32_t v = 0;
-            if (f0 + q < a.count && r0 + jj < slice_len && j < a.D) v = ks_round(gate_in(a.gv, f0 + q, a.ct_words)[j], tg);
+            const uint64_t *row = ct_ptr[q];
+            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg);
             tile[(sl * JT + jj) * 64 + q] = v;
         }
         __syncthreads();
-        for (uint32_t jj = 0; jj < JT; jj++) {
-            const uint32_t j = wave * slice_len + r0 + jj;
-            if (r0 + jj >= slice_len || j >= a.D) break;          // wave-uniform
-            const uint32_t ab = tile[(wave * JT + jj) * 64 + lane];
-            const uint64_t *krow = a.ksk + (size_t)j * a.t * a.stride + col0;   // wave-uniform address
-            for (uint32_t v = 0; v < a.t; v++) {
-                const uint64_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
+        // this wave's mask words of the round: j_lo .. j_lo + jn; their t key rows are consecutive in memory.
+        // The rows are walked as one flat sequence with the NEXT row's words requested (scalar loads) before the
+        // current row is used, so a scalar-cache miss is hidden behind a row of multiply-adds.
+        const uint32_t j_lo = wave * slice_len + r0;
+        uint32_t jn = slice_len - r0 < (uint32_t)JT ? slice_len - r0 : (uint32_t)JT;
+        if (j_lo >= a.D) jn = 0;
+        else if (j_lo + jn > a.D) jn = a.D - j_lo;
+        const uint32_t n_rows = jn * a.t;
+        const uint64_t *krow = a.ksk + (size_t)j_lo * a.t * a.stride + col0;   // wave-uniform address
+        uint64_t kw[COLS], kw_next[COLS];
+        if (n_rows) {
 #pragma unroll
-                for (int c = 0; c < COLS; c++) acc[c] += d * krow[(size_t)v * a.stride + c];
+            for (int c = 0; c < COLS; c++) kw[c] = krow[c];
+        }
+        uint32_t v = 0, jj = 0;
+        uint32_t ab = n_rows ? tile[(wave * JT) * 64 + lane] : 0u;
+        for (uint32_t row = 0; row < n_rows; row++) {
+            const uint64_t *nxt = krow + (size_t)(row + 1 < n_rows ? row + 1 : row) * a.stride;
+#pragma unroll
+            for (int c = 0; c < COLS; c++) kw_next[c] = nxt[c];
+            const uint64_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
+#pragma unroll
+            for (int c = 0; c < COLS; c++) acc[c] += d * kw[c];
+#pragma unroll
+            for (int c = 0; c < COLS; c++) kw[c] = kw_next[c];
+            if (++v == a.t) {
+                v = 0;
+                jj++;
+                if (jj < jn) ab = tile[(wave * JT + jj) * 64 + lane];
             }
         }
     }
@@ -134,7 +160,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
     }
     __syncthreads();
     if (wave || f >= a.count) return;
-    const uint64_t body = gate_in(a.gv, f, a.ct_words)[a.D];
+    const uint64_t body = ct_ptr[lane][a.D];
 #pragma unroll
     for (int c = 0; c < COLS; c++) {
         const uint32_t col = col0 + c;

@@ -95,7 +95,11 @@ struct PolyNtt {
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
                 const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
+#if FBS_EXP_NOTWLOAD   /* timing experiment only: wrong results */
+                const double w = 1234567.0 + (double)blk;
+#else
                 const double w = tw[(1u << s) + blk];
+#endif
                 const double u = x[m];
                 const double v = fp_mulmod(x[m + hm], w);
                 x[m] = u + v;
