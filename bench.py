@@ -107,7 +107,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_blind_rotate.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="hbm", kernel="k_blind_rotate<10>", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+        roofline = dict(bound="hbm", kernel="k_blind_rotate<10,6>", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=achieved / HBM_PEAK, traffic=traffic, avg_launch_ms=br_ms, bytes_per_unit=br_bytes_per_fbs,
                         units_per_launch=B, keyswitch_avg_launch_ms=ks_ms,
                         whole_path_bytes_per_fbs=prm.bytes_per_fbs(),
@@ -115,7 +115,9 @@ def main():
                         note="key stream is served from L2/MALL after first touch; the kernel is integer-VALU bound, see DESIGN.md")
         result = dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world,
                       steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                      higher_is_better=True, scaling="weak", vs_baseline=None, dtype="u64", data="synthetic",
+                      higher_is_better=True, scaling="weak", vs_baseline=None,
+                      dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)",
+                      data="synthetic",
                       config=dict(workload="BASELINE configs[1]: %d independent FBS per GPU per step, P1024 "
                                            "(n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2), p=15, 16 random tables" % B,
                                   batch_per_gpu=B, parallelism="replicas of the batch per GPU, keys replicated, no collective",
