@@ -59,21 +59,24 @@ struct PolyNtt {
     // make LDS writes of the polynomial's lanes visible to its lanes
     __device__ static __forceinline__ void sync() {
         if constexpr (LL == 6) {
-            // one wave: LDS operations complete in issue order; only the compiler must be held back
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // one wave: LDS operations complete in issue order; only the compiler must be held back, and only for
+            // LDS ("local") accesses -- global loads (twiddles, key rows) stay free to be issued early
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         } else {
             __syncthreads();
         }
     }
 
-    // Ping-pong exchange state: `bufs` = two N-word buffers of this polynomial, `pp` = which is next.
+    // Exchange state: `bufs` = the N-word buffer(s) of this polynomial, `pp` = which of two is next.  A polynomial
+    // that lives in ONE wave needs no ping-pong (its LDS operations are ordered): stride = 0 keeps a single buffer.
     struct Xchg {
         double *bufs;
         uint32_t pp;
+        uint32_t stride = N;
         __device__ __forceinline__ double *next() {
-            double *b = bufs + (pp ? N : 0);
+            double *b = bufs + (pp ? stride : 0);
             pp ^= 1u;
             return b;
         }
@@ -96,7 +99,7 @@ struct PolyNtt {
                 if (m & hm) continue;
                 const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
 #if FBS_EXP_NOTWLOAD   /* timing experiment only: wrong results */
-                const double w = 1234567.0 + (double)blk;
+                const double w = tw[(1u << s) + (uint32_t)(m >> (bit + 1))];   // lane-uniform index: scalar load
 #else
                 const double w = tw[(1u << s) + blk];
 #endif
