@@ -20,10 +20,6 @@
 
 namespace fbs {
 
-#ifndef FBS_BR_PREFETCH_KEYS
-#define FBS_BR_PREFETCH_KEYS 0
-#endif
-
 struct BrArgs {
     GateView gv;
     const uint32_t *ms;      // [count][n+1], values in [0, 2N)
@@ -160,39 +156,18 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
             const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
             const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
-#if FBS_BR_PREFETCH_KEYS
-            // issue the key-row loads before the transform: they land while the butterflies run
-            double2 ko[E / 2];
-#pragma unroll
-            for (int m = 0; m < E / 2; m++) ko[m] = k_own[m * LANES + t];
             W::forward(x, xc, t, twf);
+            // (requesting the key polynomials ahead of the transform was tried -- before the whole transform and
+            // before its last group -- and lost: the kernel sits at the 256-VGPR limit and the early loads spill)
 #pragma unroll
             for (int m = 0; m < E; m += 2) {
-                own[m] += fp_mulmod(x[m], ko[m >> 1].x);
-                own[m + 1] += fp_mulmod(x[m + 1], ko[m >> 1].y);
-            }
-#pragma unroll
-            for (int m = 0; m < E; m += 2) {
-                const double2 kt = k_oth[(m >> 1) * LANES + t];
-                other[m] += fp_mulmod(x[m], kt.x);
-                other[m + 1] += fp_mulmod(x[m + 1], kt.y);
-            }
-#else
-            W::forward(x, xc, t, twf);
-#pragma unroll
-            for (int m = 0; m < E; m += 2) {
-#if FBS_EXP_NOKEYLOAD   /* timing experiment only: wrong results */
-                const double2 ko = {1234567.0 + m, 7654321.0 + t}, kt = {2345671.0 + m, 6543217.0 + t};
-#else
                 const double2 ko = k_own[(m >> 1) * LANES + t];
                 const double2 kt = k_oth[(m >> 1) * LANES + t];
-#endif
                 own[m] += fp_mulmod(x[m], ko.x);
                 own[m + 1] += fp_mulmod(x[m + 1], ko.y);
                 other[m] += fp_mulmod(x[m], kt.x);
                 other[m + 1] += fp_mulmod(x[m + 1], kt.y);
             }
-#endif
         }
 
         // ---- hand the partner its half of the external product (same ping-pong slot in both regions) ----
@@ -225,153 +200,6 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
         }
     } else if (t == 0) {
         out[N] = fq_add(fp_to_u64(acc[0]), a.post[table]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// One wavefront per GLWE component (N <= 1024): same algorithm, tuned for the register file.  The accumulator
-// lives in LDS for the whole bootstrap (the rotation gathers straight from it, the update is a read-modify-write
-// of the lane's own words), which frees 2*E VGPRs: enough to request the step's key polynomials BEFORE the
-// transform that precedes their use, so the L2 round trip hides behind the butterflies.
-// ---------------------------------------------------------------------------------------------
-#ifndef FBS_BR_PREFETCH
-#define FBS_BR_PREFETCH 2   // 0: load keys at use; 1: own-component keys ahead of the NTT; 2: both components' keys
-#endif
-#ifndef FBS_BR_W64
-#define FBS_BR_W64 0        // 1: use this kernel whenever a polynomial fits one wave (measured slower: 17.1 vs 15.1 ms)
-#endif
-
-template <int LOGN>
-__global__ __launch_bounds__(128) void k_blind_rotate_w64(BrArgs a) {
-    using W = PolyNtt<LOGN, 6>;
-    constexpr int N = W::N, E = W::E;
-    __shared__ double lds[2 * 2 * N];             // [component][0: accumulator home, 1: exchange buffer][N]
-    const uint32_t comp = threadIdx.x >> 6;       // GLWE component owned by this wave: 0 = mask, 1 = body
-    const uint32_t t = threadIdx.x & 63;
-    double *accbuf = lds + comp * 2 * N;
-    double *xbuf = accbuf + N;
-    double *their_x = lds + (comp ^ 1u) * 2 * N + N;
-    typename W::Xchg xc{xbuf, 0, 0};
-
-    const size_t f = blockIdx.x;
-    const size_t gate = f / a.gv.s_count;
-    const uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
-    const uint32_t *ms = a.ms + f * (a.n + 1);
-    const uint64_t *tv = a.tvs + (size_t)table * N;
-    const uint32_t rows = 2 * a.l;
-
-    // word of this lane's register m in the accumulator buffer (group-0 layout: coefficient t + 64 m)
-    uint32_t home[E];
-#pragma unroll
-    for (int m = 0; m < E; m++) home[m] = W::phys(t + 64u * m);
-
-    // ACC = (0, X^{-b~} * TV), canonical
-    {
-        const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const uint32_t idx = (t + 64u * m - r) & (2u * N - 1u);
-            const uint64_t v = tv[idx & (N - 1)];
-            accbuf[home[m]] = comp ? fp_from_u64((idx & N) ? fq_neg(v) : v) : 0.0;
-        }
-        W::sync();
-    }
-
-    const uint32_t rshift = FQ_BITS - 1 - a.l * a.beta;
-    const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
-
-    uint32_t r_next = ms[0];
-    for (uint32_t i = 0; i < a.n; i++) {
-        const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
-        r_next = ms[i + 1];
-        if (r == 0) continue;
-
-        // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
-        uint32_t abar[E];
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const uint32_t idx = (t + 64u * m - r) & (2u * N - 1u);
-            const double v = accbuf[W::phys(idx & (N - 1))];
-            const double d = fp_canon(((idx & N) ? -v : v) - accbuf[home[m]]);
-            abar[m] = (uint32_t)(((fp_to_u64(d) >> rshift) + 1) >> 1);
-        }
-
-        double own[E], other[E];
-#pragma unroll
-        for (int m = 0; m < E; m++) own[m] = other[m] = 0.0;
-        for (int lv = (int)a.l - 1; lv >= 0; lv--) {
-            const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
-            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
-            const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
-#if FBS_BR_PREFETCH >= 1
-            double2 ko[E / 2];
-#pragma unroll
-            for (int m = 0; m < E / 2; m++) ko[m] = k_own[m * 64 + t];
-#endif
-#if FBS_BR_PREFETCH >= 2
-            double2 kt[E / 2];
-#pragma unroll
-            for (int m = 0; m < E / 2; m++) kt[m] = k_oth[m * 64 + t];
-#endif
-            double x[E];
-#pragma unroll
-            for (int m = 0; m < E; m++) {
-                const uint32_t dg = abar[m] & bmask;
-                const uint32_t carry = dg >= bhalf ? 1u : 0u;
-                abar[m] = (abar[m] >> a.beta) + carry;
-                x[m] = (double)((int)dg - (int)(carry << a.beta));
-            }
-            W::forward(x, xc, t, a.tw_fwd);
-#pragma unroll
-            for (int m = 0; m < E; m += 2) {
-#if FBS_BR_PREFETCH >= 1
-                const double2 k0 = ko[m >> 1];
-#else
-                const double2 k0 = k_own[(m >> 1) * 64 + t];
-#endif
-                own[m] += fp_mulmod(x[m], k0.x);
-                own[m + 1] += fp_mulmod(x[m + 1], k0.y);
-            }
-#pragma unroll
-            for (int m = 0; m < E; m += 2) {
-#if FBS_BR_PREFETCH >= 2
-                const double2 k1 = kt[m >> 1];
-#else
-                const double2 k1 = k_oth[(m >> 1) * 64 + t];
-#endif
-                other[m] += fp_mulmod(x[m], k1.x);
-                other[m + 1] += fp_mulmod(x[m + 1], k1.y);
-            }
-        }
-
-        // ---- hand the partner its half of the external product through its exchange buffer --------
-        __syncthreads();   // the partner is done with its own transforms
-#pragma unroll
-        for (int m = 0; m < E; m++) their_x[m * 64 + t] = other[m];
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < E; m++) own[m] += xbuf[m * 64 + t];
-
-        // ---- back to coefficients (the 1/N is folded into the key) and accumulate in place ---------
-        W::inverse(own, xc, t, a.tw_inv);
-        W::sync();
-#pragma unroll
-        for (int m = 0; m < E; m++) accbuf[home[m]] = fp_canon(accbuf[home[m]] + own[m]);
-        W::sync();
-    }
-
-    // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
-    uint64_t *out = gate_out(a.gv, f, a.ct_words);
-    if (comp == 0) {
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const uint32_t j = t + 64u * m;
-            const uint64_t v = fp_to_u64(accbuf[home[m]]);
-            if (j == 0) out[0] = v;
-            else out[N - j] = fq_neg(v);
-        }
-    } else if (t == 0) {
-        out[N] = fq_add(fp_to_u64(accbuf[home[0]]), a.post[table]);
     }
 }
 
@@ -458,10 +286,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     switch (p.log_n_poly) {
 #define X(L)                                                                                                           \
     case L:                                                                                                            \
-        if constexpr (lanes_log2_for(L) == 6 && FBS_BR_W64)                                                            \
-            hipLaunchKernelGGL((k_blind_rotate_w64<L>), grid, dim3(128), 0, stream, a);                                \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L)>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a); \
+        hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L)>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a);  \
         break;
         FBS_FOR_EACH_SHAPE(X)
 #undef X

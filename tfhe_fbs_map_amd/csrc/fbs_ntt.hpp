@@ -98,11 +98,7 @@ struct PolyNtt {
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
                 const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
-#if FBS_EXP_NOTWLOAD   /* timing experiment only: wrong results */
-                const double w = tw[(1u << s) + (uint32_t)(m >> (bit + 1))];   // lane-uniform index: scalar load
-#else
                 const double w = tw[(1u << s) + blk];
-#endif
                 const double u = x[m];
                 const double v = fp_mulmod(x[m + hm], w);
                 x[m] = u + v;
@@ -136,8 +132,14 @@ struct PolyNtt {
         }
     }
 
-    template <int G>
-    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
+    // `before_last` runs right before the butterflies of the last group: the place to issue global loads whose
+    // results are wanted when the transform ends (one group of butterflies ~ one L2 round trip)
+    template <int G, class Hook>
+    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw, Hook &&before_last) {
+        if constexpr (G + 1 == GROUPS) before_last();
         fwd_group<G>(x, t, tw);
         if constexpr (G + 1 < GROUPS) {
             double *buf = xc.next();
@@ -145,7 +147,7 @@ struct PolyNtt {
             store_group<G>(buf, t, x);
             sync();
             load_group<G + 1>(buf, t, x);
-            fwd_from<G + 1>(x, xc, t, tw);
+            fwd_from<G + 1>(x, xc, t, tw, before_last);
         }
     }
     template <int G>
@@ -164,7 +166,11 @@ struct PolyNtt {
     // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
     // (last-group layout, |x| < 9.3 q)
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
-        fwd_from<0>(x, xc, t, tw);
+        fwd_from<0>(x, xc, t, tw, NoHook{});
+    }
+    template <class Hook>
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const double *tw, Hook &&before_last) {
+        fwd_from<0>(x, xc, t, tw, before_last);
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q)
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
