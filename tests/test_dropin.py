@@ -1,0 +1,52 @@
+"""Drop-in checks on the CPU: the module-name shim, and -- where the reference is present (build container only) --
+the REFERENCE's own mappers building their programs into this package's LutExecEnv, byte-identical to what they
+build into the reference's."""
+import io
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import load_fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/fbs_mapper"
+
+
+def test_module_name_shim():
+    code = ("import sys; sys.path.insert(0, %r); from fbs_exec_env import *; "
+            "e = LutExecEnv(); a = e.input('a'); b = e.input('b'); "
+            "m = e.bootstrap(e.linear([1, 2], [a, b]), [0, 1, 1, 0]); e.output('o', m); "
+            "import io; s = io.StringIO(); e.print(os=s, show_outputs=True); print(s.getvalue(), end='')" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
+    assert out == "m1 = 1 * a + 2 * b \nm2 = Bootstrap(m1, [0, 1, 1, 0])\nOutput o = m2\n"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("mapper,p,fixture", [("search", 7, "full_adder__search_p7"), ("naive", 7, "aoi21__naive_p7"),
+                                              ("search", 15, "aes_sbox__search_p15"), ("basic", 2, "ascon_lut__basic_p2")])
+def test_reference_mappers_build_into_this_env(mapper, p, fixture):
+    """Run the reference's map_to_fbs (imported read-only, in a subprocess) with OUR fbs_exec_env shadowing
+    theirs: the mapped program text must equal the fixture the reference produced with its own class."""
+    circuit = fixture.split("__")[0]
+    gen = {"full_adder": "full_adder_bench", "aoi21": "aoi21_bench", "aes_sbox": "aes_sbox", "ascon_lut": "ascon_lut"}[circuit]
+    code = f"""
+import sys, io, logging
+sys.dont_write_bytecode = True
+sys.argv = ['x']
+sys.path.insert(0, '/root/reference'); sys.path.insert(0, '/root/reference/experiments'); sys.path.insert(0, {REF!r})
+sys.path.insert(0, {ROOT!r})                      # our fbs_exec_env shadows fbs_mapper/fbs_exec_env.py
+import fbs_exec_env
+assert 'tfhe_fbs_map_amd' in fbs_exec_env.LutExecEnv.__module__
+import bit_exec_env, map_to_fbs, generate_benchmarks as gb
+logging.disable(logging.CRITICAL)
+env = bit_exec_env.BitExecEnv(); gb.Bit.set_env(env); gb.{gen}(); env.remove_dangling_nodes()
+m = map_to_fbs.MapToFBSBasic() if {mapper!r} == 'basic' else map_to_fbs.MapToFBSHeur(fbs_size={p}, max_fbs_size={2 * p}, max_truth_table_size=16, cone_merger={mapper!r})
+lut = m.map(env); lut.remove_dangling_nodes()
+assert type(lut).__module__.startswith('tfhe_fbs_map_amd')
+s = io.StringIO(); lut.print(os=s, show_outputs=True); sys.stdout.write(s.getvalue())
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1")).stdout
+    assert out == load_fixture(fixture)["fbs"]

@@ -76,3 +76,12 @@ def test_config5_p31_on_n2048():
     from tfhe_fbs_map_amd import ExecConfig
     run("adder128__search_p31", 8, ExecConfig())          # params_for(31) -> N = 2048
     run("full_adder__naive_p31", 32, ExecConfig())
+
+
+def test_config4_full_trivium_stream(cfg15):
+    """BASELINE config 4 stand-in: the reference's trivium_stream_v2 (generate_benchmarks.py:389-414) mapped @15 by
+    the reference's search mapper: 8 760 bootstraps, depth 33, ~300 gates per level; 16 samples = 140 160 FBS."""
+    from tests.helpers import fixture_names
+    if "trivium_stream_v2__search_p15" not in fixture_names():
+        pytest.skip("big fixture not captured")
+    run("trivium_stream_v2__search_p15", 16, cfg15)

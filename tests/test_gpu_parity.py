@@ -233,3 +233,20 @@ def test_level_runner_on_gpu_equals_program_eval(nat, toy_params):
         assert np.array_equal(got, ref), cls.__name__
     for k, name in enumerate(low["out_names"]):
         assert np.array_equal(ctx.decrypt(ref[k]), expect[name])
+
+
+def test_output_noise_stays_inside_the_box(p1024_pair):
+    """Size-independent property at the full batch: the phase of every bootstrapped ciphertext sits within a small
+    fraction of the half box q/4p around its message (reduced-noise default; see params.margin_sigmas)."""
+    ctx, o = p1024_pair
+    rng = np.random.default_rng(7)
+    table = [0] + [int(v) for v in rng.integers(0, 2, 14)]
+    B = 512
+    msgs = rng.integers(0, 15, B)
+    out = ctx.bootstrap_batch(ctx.tvset([table]), ctx.encrypt(msgs, nonce0=4000))
+    phase = o.phase(out).astype(object)
+    delta = 2 * o.delta_half
+    want = np.array([table[m] for m in msgs], dtype=object) * delta
+    err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
+    half_box = orc.Q / (4 * 15)
+    assert err.max() < 0.05 * half_box, err.max() / half_box

@@ -6,7 +6,7 @@ the hand-written gfx950 kernels.  Importing the package loads the shared library
 if it has not been built -- there is no CPU execution path here.
 """
 from . import _native
-from ._native import Context, FbsError, Params, Program, TvSet
+from ._native import MODULUS, MODULUS_BITS, Context, FbsError, Params, Program, TvSet
 from .fbs_exec_env import ExecConfig, FbsExecEnv, LutExecEnv, min_fbs_size, parse_fbs, parse_lbf, table_is_valid
 from .params import P1024, P2048, margin_sigmas, params_for
 

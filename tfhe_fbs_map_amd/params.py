@@ -18,7 +18,9 @@ import math
 from ._native import MODULUS, Params
 
 P1024 = Params()                                            # n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2
-P2048 = Params(n=630, log_n_poly=11, l_bsk=3, beta_bsk=7)   # p = 31 needs the wider accumulator
+# p = 31 needs the wider accumulator, and its linear combinations (norm2 up to ~325) need a finer decomposition:
+# with l*beta = 21 bits the rounding of the decomposition alone (n(1+N/2)/(12 B^2l)) times 325 eats the box
+P2048 = Params(n=630, log_n_poly=11, l_bsk=4, beta_bsk=6)
 
 
 def params_for(p: int, norm2: int | None = None) -> Params:
