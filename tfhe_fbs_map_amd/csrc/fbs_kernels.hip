@@ -102,9 +102,15 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
     const uint32_t dmask = (1u << a.gamma) - 1u;
     const uint32_t slice_len = (a.D + 3) / 4;    // mask words per wave
 
-    uint64_t acc[COLS];
+    // two accumulators per column: digit x low word (one v_mad_u64_u32) and digit x high 14 bits (one 24-bit mad);
+    // neither can overflow (dev_supported), and there is no carry to move between registers in the loop
+    uint64_t acc_lo[COLS];
+    uint32_t acc_hi[COLS];
 #pragma unroll
-    for (int c = 0; c < COLS; c++) acc[c] = 0;
+    for (int c = 0; c < COLS; c++) {
+        acc_lo[c] = 0;
+        acc_hi[c] = 0;
+    }
     if (threadIdx.x < 64) ct_ptr[threadIdx.x] = f < a.count ? gate_in(a.gv, f, a.ct_words) : nullptr;
 
     for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
@@ -119,35 +125,27 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
             tile[(sl * JT + jj) * 64 + q] = v;
         }
         __syncthreads();
-        // this wave's mask words of the round: j_lo .. j_lo + jn; their t key rows are consecutive in memory.
-        // The rows are walked as one flat sequence with the NEXT row's words requested (scalar loads) before the
-        // current row is used, so a scalar-cache miss is hidden behind a row of multiply-adds.
-        const uint32_t j_lo = wave * slice_len + r0;
-        uint32_t jn = slice_len - r0 < (uint32_t)JT ? slice_len - r0 : (uint32_t)JT;
-        if (j_lo >= a.D) jn = 0;
-        else if (j_lo + jn > a.D) jn = a.D - j_lo;
-        const uint32_t n_rows = jn * a.t;
-        const uint64_t *krow = a.ksk + (size_t)j_lo * a.t * a.stride + col0;   // wave-uniform address
-        uint64_t kw[COLS], kw_next[COLS];
-        if (n_rows) {
+        // this wave's mask words of the round.  The key-row address depends only on (wave, jj, v): the compiler keeps
+        // it in SGPRs and fetches the COLS words with one s_load_dwordx16 (checked in the ISA: a hand-rolled
+        // "next row" prefetch made it fall back to 64-lane vector loads of one address and ran 40 % slower).
+        for (uint32_t jj = 0; jj < JT; jj++) {
+            const uint32_t j = wave * slice_len + r0 + jj;
+            if (r0 + jj >= slice_len || j >= a.D) break;          // wave-uniform
+            const uint32_t ab = tile[(wave * JT + jj) * 64 + lane];
+            // constant address space: the key is read-only for the life of the kernel and the address is wave-uniform,
+            // so these become scalar loads (s_load_dwordx16).  As plain global loads they are 64-lane broadcasts that
+            // saturate the vector memory address path (measured: 1.2 ms instead of 0.x ms per 1024-batch).
+            typedef const uint64_t __attribute__((address_space(4))) *const_words;
+            const const_words krow = (const_words)(uintptr_t)(a.ksk + (size_t)j * a.t * a.stride + col0);
+#pragma unroll 4
+            for (uint32_t v = 0; v < a.t; v++) {
+                const uint32_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
 #pragma unroll
-            for (int c = 0; c < COLS; c++) kw[c] = krow[c];
-        }
-        uint32_t v = 0, jj = 0;
-        uint32_t ab = n_rows ? tile[(wave * JT) * 64 + lane] : 0u;
-        for (uint32_t row = 0; row < n_rows; row++) {
-            const uint64_t *nxt = krow + (size_t)(row + 1 < n_rows ? row + 1 : row) * a.stride;
-#pragma unroll
-            for (int c = 0; c < COLS; c++) kw_next[c] = nxt[c];
-            const uint64_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
-#pragma unroll
-            for (int c = 0; c < COLS; c++) acc[c] += d * kw[c];
-#pragma unroll
-            for (int c = 0; c < COLS; c++) kw[c] = kw_next[c];
-            if (++v == a.t) {
-                v = 0;
-                jj++;
-                if (jj < jn) ab = tile[(wave * JT + jj) * 64 + lane];
+                for (int c = 0; c < COLS; c++) {
+                    const uint64_t kw = krow[(size_t)v * a.stride + c];
+                    acc_lo[c] += (uint64_t)d * (uint32_t)kw;
+                    acc_hi[c] += __umul24(d, (uint32_t)(kw >> 32));
+                }
             }
         }
     }
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
     uint64_t *park = reinterpret_cast<uint64_t *>(tile);
     if (wave) {
 #pragma unroll
-        for (int c = 0; c < COLS; c++) park[((wave - 1) * COLS + c) * 64 + lane] = acc[c];
+        for (int c = 0; c < COLS; c++) park[((wave - 1) * COLS + c) * 64 + lane] = acc_lo[c] + ((uint64_t)acc_hi[c] << 32);
     }
     __syncthreads();
     if (wave || f >= a.count) return;
@@ -165,7 +163,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
     for (int c = 0; c < COLS; c++) {
         const uint32_t col = col0 + c;
         if (col > a.n) break;
-        uint64_t sum = acc[c];
+        uint64_t sum = acc_lo[c] + ((uint64_t)acc_hi[c] << 32);
 #pragma unroll
         for (int w = 0; w < 3; w++) sum += park[(w * COLS + c) * 64 + lane];
         a.ms[f * (a.n + 1) + col] = ks_finish(sum, col == a.n ? body : 0, a.log2_2n);
@@ -230,7 +228,8 @@ int dev_supported(const fbs_ctx *ctx) {
     if ((p.k + 1) * p.l_bsk > 20) return set_error(ctx, FBS_E_INVALID, "need (k+1)*l <= 20");
     // 64-bit key-switch accumulators: D*t digits < 2^gamma times words < 2^46
     double bits = FQ_BITS + p.gamma_ksk + std::log2((double)p.t_ksk * ctx->D);
-    if (bits > 63.9) return set_error(ctx, FBS_E_INVALID, "key-switch accumulator would overflow 64 bits");
+    if (bits > 63.9 || bits - 32.0 > 31.9)   // whole sum in 64 bits; the high-word partial sums in 32
+        return set_error(ctx, FBS_E_INVALID, "key-switch accumulator would overflow");
     return FBS_OK;
 }
 
