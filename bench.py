@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="independent FBS per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 32 per thread, 0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +142,7 @@ def cpu_baseline(prm, tables, cts, ids, gpu_out, sample):
         pass
     cores = min(cores, 16)          # a one-GPU box is a 16-core share of the host; oversubscribing it only thrashes
     if sample < 0:
-        sample = min(len(cts), 32 * cores)
+        sample = min(len(cts), 64 * cores)
     sample = max(1, min(sample, len(cts)))
     orc = tfhe_oracle.Oracle(prm, seed=1)
     t0 = time.perf_counter()

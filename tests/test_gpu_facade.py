@@ -85,3 +85,29 @@ def test_config4_full_trivium_stream(cfg15):
     if "trivium_stream_v2__search_p15" not in fixture_names():
         pytest.skip("big fixture not captured")
     run("trivium_stream_v2__search_p15", 16, cfg15)
+
+
+def test_scalar_and_broadcast_inputs(cfg15):
+    """The reference reshapes every input with np.array(v).reshape(-1) (fbs_exec_env.py:213-214): scalars and
+    length-1 lists are legal and broadcast against longer inputs."""
+    from tfhe_fbs_map_amd import LutExecEnv
+    env = LutExecEnv()
+    a, b = env.input("a"), env.input("b")
+    x = env.bootstrap(env.linear([1, 2], [a, b]), [0, 1, 1, 0])          # XOR-ish table on a + 2b
+    env.output("x", x)
+    env.output("k", env.const(1))
+    out = env.eval({"a": 1, "b": 0}, config=cfg15)
+    assert out["x"].tolist() == [1] and out["k"] == 1
+    out = env.eval({"a": [0, 1, 0, 1], "b": [1]}, config=cfg15)
+    assert out["x"].tolist() == [1, 0, 1, 0]
+
+
+def test_fbs_size_too_small_is_an_assertion(cfg15):
+    from tfhe_fbs_map_amd import ExecConfig, LutExecEnv
+    env = LutExecEnv()
+    a, b, c = env.input("a"), env.input("b"), env.input("c")
+    s = env.linear([1, 2, 4], [a, b, c])
+    env.output("o", env.bootstrap(s, [0, 1, 1, 0, 1, 0, 0, 0]))
+    with pytest.raises(AssertionError):
+        env.eval({"a": [0], "b": [1], "c": [1]}, config=ExecConfig(fbs_size=3))
+    assert env.eval({"a": [0], "b": [1], "c": [1]}, config=cfg15)["o"].tolist() == [0]
