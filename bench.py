@@ -112,7 +112,8 @@ def main():
                         units_per_launch=B, keyswitch_avg_launch_ms=ks_ms,
                         whole_path_bytes_per_fbs=prm.bytes_per_fbs(),
                         whole_path_frac=value / world * prm.bytes_per_fbs() / HBM_PEAK,
-                        note="key stream is served from L2/MALL after first touch; the kernel is integer-VALU bound, see DESIGN.md")
+                        note="achieved/frac are ALGORITHMIC bytes over time; the key stream is served from L2/MALL after first "
+                             "touch (traffic = PMC-measured fabric bytes per launch) and the kernel is VALU (FP64-rate) bound, see DESIGN.md")
         result = dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world,
                       steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                       higher_is_better=True, scaling="weak", vs_baseline=None,

@@ -61,3 +61,33 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 # prose may mention the checker; code must not import, open or link it
                 assert not re.search(r"(import\s+oracle|from\s+oracle|oracle[./]|libtfhe_oracle|tfhe_oracle|lut_oracle|orc_)", src), f
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "capi_smoke")
+    lib_dir = os.path.join(ROOT, "tfhe_fbs_map_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "capi_smoke.c"), "-o", exe,
+                           "-L", lib_dir, "-lfbsexec", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """A C11 program includes include/fbs_exec.h, links libfbsexec.so and calls it; without a GPU the library
+    must answer FBS_E_DEVICE (exit code 3), not crash and not compute."""
+    import subprocess
+    import torch
+    exe = _build_c_client(tmp_path)
+    rc = subprocess.run([exe], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert rc.returncode == 0, rc.stdout + rc.stderr
+    else:
+        assert rc.returncode == 3, rc.stdout + rc.stderr
+
+
+@pytest.mark.gpu
+def test_c_client_bootstraps_on_the_gpu(tmp_path):
+    import subprocess
+    rc = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True)
+    assert rc.returncode == 0 and rc.stdout.startswith("ok on gfx950"), rc.stdout + rc.stderr
