@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 
 // ---------------------------------------------------------------------------------------------
 template <int LOGN, int LL>
-__global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
+__global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = PolyNtt<LOGN, LL>;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds[2 * 2 * N];             // [component][ping-pong][N]
@@ -115,8 +115,10 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
         }
     }
 
-    const uint32_t rshift = FQ_BITS - 1 - a.l * a.beta;
-    const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
+    // Rounding and digit extraction run on doubles too (floor(x * 2^-s + 1/2) is exact on integers):
+    //   abar = (d + 2^(s-1)) >> s,  s = 46 - l*beta;   next = (abar + B/2) >> beta;   digit = abar - B * next
+    const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
+    const double base = fp_exp2i((int)a.beta), base_inv = fp_exp2i(-(int)a.beta);
 
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
     for (uint32_t i = 0; i < a.n; i++) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
         if (r == 0) continue;   // X^0 * ACC - ACC = 0: nothing to add (uniform over the workgroup)
 
         // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
-        uint32_t abar[E];
+        double abar[E];
         {
             double *buf = xc.next();
             if constexpr (LL == 6) W::sync();
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
             for (int m = 0; m < E; m++) {
                 const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
                 const double v = buf[W::phys(idx & (N - 1))];
-                const double d = fp_canon(((idx & N) ? -v : v) - acc[m]);      // (-2q, q) -> [0, q)
-                abar[m] = (uint32_t)(((fp_to_u64(d) >> rshift) + 1) >> 1);
+                const double d = fp_canon_near(((idx & N) ? -v : v) - acc[m]);      // (-2q, q) -> [0, q)
+                abar[m] = __builtin_floor(__builtin_fma(d, round_scale, 0.5));
             }
         }
 
@@ -148,10 +150,9 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
             double x[E];
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const uint32_t dg = abar[m] & bmask;
-                const uint32_t carry = dg >= bhalf ? 1u : 0u;
-                abar[m] = (abar[m] >> a.beta) + carry;
-                x[m] = (double)((int)dg - (int)(carry << a.beta));   // balanced digit in [-B/2, B/2)
+                const double next = __builtin_floor(__builtin_fma(abar[m], base_inv, 0.5));
+                x[m] = __builtin_fma(-next, base, abar[m]);   // balanced digit in [-B/2, B/2)
+                abar[m] = next;
             }
             const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(2 << LL) void k_blind_rotate(BrArgs a) {
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
         W::inverse(own, xc, t, twi);
 #pragma unroll
-        for (int m = 0; m < E; m++) acc[m] = fp_canon(acc[m] + own[m]);
+        for (int m = 0; m < E; m++) acc[m] = fp_canon_near(acc[m] + own[m]);   // |.| <= 9 q
     }
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------

@@ -80,6 +80,17 @@ FBS_D double fp_canon(double x) {
     const double c = fp_center(x);
     return c < 0.0 ? c + FP_Q : c;
 }
+// canonical representative in [0, q) of an integer |x| <= 12 q, 3 instructions.  floor(x/q) is exact here: integers
+// that are not multiples of q sit at least 2^-46 away from an integer quotient (rounding error < 2^-48), and the
+// multiples k*q, |k| <= 12, give exactly k (checked below for this q and this rounding of 1/q).
+FBS_D double fp_canon_near(double x) { return __builtin_fma(-__builtin_floor(x * FP_QINV), FP_Q, x); }
+#define FBS_CHECK_MULTIPLE(k) static_assert(((k) * FP_Q) * FP_QINV == (k), "k*q/q must be exact")
+FBS_CHECK_MULTIPLE(1.0); FBS_CHECK_MULTIPLE(2.0); FBS_CHECK_MULTIPLE(3.0); FBS_CHECK_MULTIPLE(4.0);
+FBS_CHECK_MULTIPLE(5.0); FBS_CHECK_MULTIPLE(6.0); FBS_CHECK_MULTIPLE(7.0); FBS_CHECK_MULTIPLE(8.0);
+FBS_CHECK_MULTIPLE(9.0); FBS_CHECK_MULTIPLE(10.0); FBS_CHECK_MULTIPLE(11.0); FBS_CHECK_MULTIPLE(12.0);
+#undef FBS_CHECK_MULTIPLE
+// 2^e as a double, e in the normal range
+FBS_D double fp_exp2i(int e) { return __longlong_as_double((long long)(1023 + e) << 52); }
 // integer-valued double in [0, 2^52) <-> uint64
 FBS_D uint64_t fp_to_u64(double x) { return (uint64_t)__double_as_longlong(x + FP_MAGIC) & 0x000FFFFFFFFFFFFFull; }
 FBS_D double fp_from_u64(uint64_t v) {   // v < 2^52
