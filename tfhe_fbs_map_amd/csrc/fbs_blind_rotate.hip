@@ -131,13 +131,17 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         {
             double *buf = xc.next();
             if constexpr (LL == 6) W::sync();
-            W::template store_group<0>(buf, t, acc);
+            // both the store and the rotated read walk consecutive words across the lanes: no swizzle needed here
+#pragma unroll
+            for (int m = 0; m < E; m++) buf[t + (uint32_t)LANES * m] = acc[m];
             W::sync();
+            const uint32_t from = (t - r) & (2u * N - 1u);   // coefficient t of X^r * ACC is +-ACC[(t - r) mod 2N]
 #pragma unroll
             for (int m = 0; m < E; m++) {
-                const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
-                const double v = buf[W::phys(idx & (N - 1))];
-                const double d = fp_canon_near(((idx & N) ? -v : v) - acc[m]);      // (-2q, q) -> [0, q)
+                const uint32_t idx = from + (uint32_t)LANES * m;   // < 3N: bit LOGN = sign, bits below = position
+                const double w = buf[idx & (N - 1)];
+                const double v = __hiloint2double(__double2hiint(w) + (int)((idx & N) << (31 - LOGN)), __double2loint(w));
+                const double d = fp_canon_near(v - acc[m]);      // (-2q, q) -> [0, q)
                 abar[m] = __builtin_floor(__builtin_fma(d, round_scale, 0.5));
             }
         }
@@ -158,8 +162,8 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
             const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
             W::forward(x, xc, t, twf);
-            // (requesting the key polynomials ahead of the transform was tried -- before the whole transform and
-            // before its last group -- and lost: the kernel sits at the 256-VGPR limit and the early loads spill)
+            // (requesting the key polynomials, or half of one, ahead of the transform or of its last group was tried
+            // repeatedly and lost every time: the kernel sits at the 256-VGPR limit and the early loads spill)
 #pragma unroll
             for (int m = 0; m < E; m += 2) {
                 const double2 ko = k_own[(m >> 1) * LANES + t];
