@@ -343,6 +343,36 @@ def edge_programs():
     dump_case("edge_nomerge", env, vals, None, dict(circuit="edge", mapper="hand"))
 
 
+def dump_netlists():
+    """Gate-level side: the netlists themselves as the reference serialises them (`BitExecEnv.to_blif`
+    bit_exec_env.py:247-279, `print` :161-171, `stats` :206-245) with seed-42 inputs and `eval` outputs, so the
+    build's BLIF reader, container and one-gate-one-bootstrap lowering are pinned without the reference."""
+    cases = {name: gen_from_reference(fn) for name, fn in SMALL_GENERATORS.items()}
+    cases["adder8"] = ripple_adder(8)
+    cases["mul4"] = array_multiplier(4)
+    rec = {}
+    for name, build in cases.items():
+        env = build()
+        blif = io.StringIO()
+        env.to_blif(fs=blif, model_name=name)
+        text = io.StringIO()
+        env.print(os=text)
+        vals = harness_inputs([i.name for i in env.inputs], 64)
+        out = env.eval(vals)
+        basic = io.StringIO()
+        lut = map_to_fbs.MapToFBSBasic().map(env)
+        lut.print(show_outputs=True, os=basic)
+        rec[name] = dict(blif=blif.getvalue(), print=text.getvalue(),
+                         stats={k: int(v) for k, v in env.stats().items()},
+                         inputs={k: encode_values(np.asarray(v)) for k, v in vals.items()},
+                         outputs={str(k): encode_values(v) for k, v in out.items()},
+                         basic_fbs=basic.getvalue())
+    path = os.path.join(OUT_DIR, "_netlists.json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(rec, sort_keys=True).encode())
+    print("netlists: %d circuits -> %s" % (len(rec), os.path.basename(path)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true",
@@ -354,6 +384,8 @@ def main():
     def want(n):
         return args.only is None or args.only in n
 
+    if want("netlists"):
+        dump_netlists()
     if want("demo"):
         demo_fbs_exec_env()
         demo_map_to_fbs()

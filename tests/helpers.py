@@ -10,7 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def fixture_names(pattern="*"):
-    return sorted(os.path.basename(p)[:-len(".json.gz")] for p in glob.glob(os.path.join(GOLDEN, pattern + ".json.gz")))
+    names = (os.path.basename(p)[:-len(".json.gz")] for p in glob.glob(os.path.join(GOLDEN, pattern + ".json.gz")))
+    return sorted(n for n in names if not n.startswith("_"))        # _*.json.gz: collections, not one program each
 
 
 def _decode(v):

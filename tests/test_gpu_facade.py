@@ -111,3 +111,50 @@ def test_fbs_size_too_small_is_an_assertion(cfg15):
     with pytest.raises(AssertionError):
         env.eval({"a": [0], "b": [1], "c": [1]}, config=ExecConfig(fbs_size=3))
     assert env.eval({"a": [0], "b": [1], "c": [1]}, config=cfg15)["o"].tolist() == [0]
+
+
+def test_blif_netlist_to_encrypted_evaluation(cfg15):
+    """Front door: BLIF text (as the reference writes it) -> gate-per-bootstrap program -> GPU, against the
+    netlist's own cleartext outputs (tests/golden/_netlists.json.gz)."""
+    import gzip
+    import json
+    import os
+    from tests.helpers import GOLDEN, _decode
+    from tfhe_fbs_map_amd.netlist import map_basic, parse_blif
+    with gzip.open(os.path.join(GOLDEN, "_netlists.json.gz"), "rb") as f:
+        netlists = json.loads(f.read().decode())
+    for case in ("full_adder", "adder8", "mul4", "aes_sbox"):
+        rec = netlists[case]
+        bits = parse_blif(rec["blif"])
+        ins = {k: _decode(v)[:32] for k, v in rec["inputs"].items()}
+        expect = {k: _decode(v)[:32] for k, v in rec["outputs"].items()}
+        assert_outputs_equal(bits.eval(ins), expect)
+        got = map_basic(bits).eval(ins, config=cfg15)
+        assert_outputs_equal(got, expect)
+
+
+def test_command_line_front_end(tmp_path, capsys):
+    """`python -m tfhe_fbs_map_amd file` on a BLIF netlist and on the mapped program the reference printed."""
+    import gzip
+    import json
+    import os
+    from tests.helpers import GOLDEN
+    from tfhe_fbs_map_amd.__main__ import main
+    with gzip.open(os.path.join(GOLDEN, "_netlists.json.gz"), "rb") as f:
+        blif = json.loads(f.read().decode())["adder8"]["blif"]
+    path = tmp_path / "adder8.blif"
+    path.write_text(blif)
+    assert main([str(path), "--samples", "16"]) == 0
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["matches_cleartext_netlist"] is True and line["type"] == "blif" and line["stats"]["nb_bootstrap"] > 0
+
+    rec = load_fixture("adder8__search_p15")
+    path = tmp_path / "adder8.fbs"
+    path.write_text(rec["fbs"])
+    assert main([str(path), "--samples", "16", "--inputs", ",".join(rec["harness_inputs"])]) == 0
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    from oracle import lut_oracle
+    np.random.seed(42)                  # the harness's draw for 16 samples (map_circuit.py:137-139)
+    ins = {name: np.random.randint(0, 2, (16)) for name in rec["harness_inputs"]}
+    expect = lut_oracle.eval_fbs_text(rec["fbs"], ins)
+    assert line["outputs"] == {k: int(np.sum(v)) for k, v in expect.items()}
