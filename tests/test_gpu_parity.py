@@ -250,3 +250,8 @@ def test_output_noise_stays_inside_the_box(p1024_pair):
     err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
     half_box = orc.Q / (4 * 15)
     assert err.max() < 0.05 * half_box, err.max() / half_box
+    # and the noise model the parameter choice rests on (params.variances) predicts what is measured
+    from tfhe_fbs_map_amd.params import P1024, variances
+    predicted = np.sqrt(variances(P1024.replace(p_msg=15))[0]) * orc.Q
+    measured = float(np.sqrt(np.mean(err ** 2)))
+    assert 0.7 * predicted < measured < 1.3 * predicted, (measured, predicted)

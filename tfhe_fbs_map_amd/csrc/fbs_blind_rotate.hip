@@ -115,10 +115,13 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         }
     }
 
-    // Rounding and digit extraction run on doubles too (floor(x * 2^-s + 1/2) is exact on integers):
-    //   abar = (d + 2^(s-1)) >> s,  s = 46 - l*beta;   next = (abar + B/2) >> beta;   digit = abar - B * next
+    // Rounding runs on doubles too (floor(x * 2^-s + c) is exact on integers): abar = (d + 2^(s-1)) >> s with
+    // s = 46 - l*beta.  Adding B/2 at every digit position turns the balanced digits (each in [-B/2, B/2), carries
+    // included) into plain bit fields:  digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
-    const double base = fp_exp2i((int)a.beta), base_inv = fp_exp2i(-(int)a.beta);
+    const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
+    double round_offset = 0.5;
+    for (uint32_t j = 0; j < a.l; j++) round_offset += (double)(bhalf << (j * a.beta));
 
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
     for (uint32_t i = 0; i < a.n; i++) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         if (r == 0) continue;   // X^0 * ACC - ACC = 0: nothing to add (uniform over the workgroup)
 
         // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
-        double abar[E];
+        uint32_t digits[E];
         {
             double *buf = xc.next();
             if constexpr (LL == 6) W::sync();
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
                 const double w = buf[idx & (N - 1)];
                 const double v = __hiloint2double(__double2hiint(w) + (int)((idx & N) << (31 - LOGN)), __double2loint(w));
                 const double d = fp_canon_near(v - acc[m]);      // (-2q, q) -> [0, q)
-                abar[m] = __builtin_floor(__builtin_fma(d, round_scale, 0.5));
+                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset);   // truncation = floor, < 2^(l*beta+1)
             }
         }
 
@@ -151,13 +154,11 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] = other[m] = 0.0;
         for (int lv = (int)a.l - 1; lv >= 0; lv--) {
+            const uint32_t shift = ((uint32_t)a.l - 1u - (uint32_t)lv) * a.beta;
             double x[E];
 #pragma unroll
-            for (int m = 0; m < E; m++) {
-                const double next = __builtin_floor(__builtin_fma(abar[m], base_inv, 0.5));
-                x[m] = __builtin_fma(-next, base, abar[m]);   // balanced digit in [-B/2, B/2)
-                abar[m] = next;
-            }
+            for (int m = 0; m < E; m++)
+                x[m] = (double)((int)((digits[m] >> shift) & bmask) - (int)bhalf);   // balanced digit in [-B/2, B/2)
             const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
             const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
