@@ -173,13 +173,22 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             });
 #pragma unroll
             for (int m = EARLY; m < E / 2; m++) ko[m] = k_own[m * LANES + t];
+            // own products first; each finished pair frees the registers its key words sat in, and the partner's
+            // key words are requested into them while the remaining own products run
+            double2 kt[E / 2];
 #pragma unroll
-            for (int m = 0; m < E; m += 2) {
-                const double2 kt = k_oth[(m >> 1) * LANES + t];
-                own[m] += fp_mulmod(x[m], ko[m >> 1].x);
-                own[m + 1] += fp_mulmod(x[m + 1], ko[m >> 1].y);
-                other[m] += fp_mulmod(x[m], kt.x);
-                other[m + 1] += fp_mulmod(x[m + 1], kt.y);
+            for (int j = 0; j < E / 2; j++) {
+                own[2 * j] += fp_mulmod(x[2 * j], ko[j].x);
+                own[2 * j + 1] += fp_mulmod(x[2 * j + 1], ko[j].y);
+                kt[j] = k_oth[j * LANES + t];
+#ifdef FBS_BR_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) {
+                other[2 * j] += fp_mulmod(x[2 * j], kt[j].x);
+                other[2 * j + 1] += fp_mulmod(x[2 * j + 1], kt[j].y);
             }
         }
 
