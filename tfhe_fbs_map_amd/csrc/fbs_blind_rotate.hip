@@ -42,7 +42,7 @@ __global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__res
         double x[W::E];
 #pragma unroll
         for (int m = 0; m < W::E; m++) x[m] = fp_from_u64(src[p * W::N + W::template index_of<0>(t, m)]);
-        W::forward(x, xc, t, tw_fwd);
+        W::forward(x, xc, t, Twiddles(tw_fwd, tw_fwd));
 #pragma unroll
         for (int m = 0; m < W::E; m++) dst[p * W::N + W::key_word(t, m)] = fp_center(fp_mulmod(x[m], n_inv));
     }
@@ -61,11 +61,11 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
         x[m] = fp_from_u64(a[W::template index_of<0>(t, m)]);
         y[m] = fp_from_u64(b[W::template index_of<0>(t, m)]);
     }
-    W::forward(x, xc, t, tw_fwd);
-    W::forward(y, xc, t, tw_fwd);
+    W::forward(x, xc, t, Twiddles(tw_fwd, tw_fwd));
+    W::forward(y, xc, t, Twiddles(tw_fwd, tw_fwd));
 #pragma unroll
     for (int m = 0; m < W::E; m++) x[m] = fp_mulmod(fp_mulmod(x[m], fp_center(y[m])), n_inv);
-    W::inverse(x, xc, t, tw_inv);
+    W::inverse(x, xc, t, Twiddles(tw_inv, tw_inv));
 #pragma unroll
     for (int m = 0; m < W::E; m++) c[W::template index_of<0>(t, m)] = fp_to_u64(fp_canon(x[m]));
 }
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     double *mine = lds + comp * 2 * N;
     double *theirs = lds + (comp ^ 1u) * 2 * N;
     typename W::Xchg xc{mine, 0};
-    const double *twf = a.tw_fwd, *twi = a.tw_inv;
+    Twiddles twf(a.tw_fwd, a.tw_fwd), twi(a.tw_inv, a.tw_inv);
     if constexpr (LL == 6) {
         // A polynomial that lives in one wave needs no ping-pong buffer; the spare half of each component's region
         // holds a twiddle table instead (forward in component 0's, inverse in component 1's), so the per-lane
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
         for (int m = 0; m < E; m++) table[t + (uint32_t)LANES * m] = src[t + (uint32_t)LANES * m];
         __syncthreads();
-        twf = lds + N;
-        twi = lds + 3 * N;
+        twf.lane = lds + N;
+        twi.lane = lds + 3 * N;
     }
 
     const size_t f = blockIdx.x;

@@ -21,6 +21,17 @@
 
 namespace fbs {
 
+// One twiddle table, two ways in: `lane` for per-lane gathers (global memory, or a copy in LDS), `uniform` for the
+// stages whose twiddle index is the same in every lane of the polynomial -- read through the scalar cache into
+// SGPRs (constant address space: the table is never written while a kernel runs), costing no VGPR and no LDS slot.
+typedef const double __attribute__((address_space(4))) *uniform_doubles;
+struct Twiddles {
+    const double *lane;
+    uniform_doubles uniform;
+    __device__ __forceinline__ Twiddles(const double *lane_table, const double *global_table)
+        : lane(lane_table), uniform((uniform_doubles)(uintptr_t)global_table) {}
+};
+
 template <int LOGN, int LL>
 struct PolyNtt {
     static constexpr int N = 1 << LOGN;
@@ -84,7 +95,7 @@ struct PolyNtt {
 
     // Cooley-Tukey stages of group G on registers
     template <int G>
-    __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const double *__restrict__ tw) {
+    __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
@@ -98,7 +109,8 @@ struct PolyNtt {
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
                 const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
-                const double w = tw[(1u << s) + blk];
+                // lo >= LL: the lane's high part is empty, the index depends on the register only
+                const double w = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)(m >> (bit + 1))] : tw.lane[(1u << s) + blk];
                 const double u = x[m];
                 const double v = fp_mulmod(x[m + hm], w);
                 x[m] = u + v;
@@ -108,7 +120,7 @@ struct PolyNtt {
     }
     // Gentleman-Sande stages of group G, last stage first
     template <int G>
-    __device__ static __forceinline__ void inv_group(double (&x)[E], uint32_t t, const double *__restrict__ tw) {
+    __device__ static __forceinline__ void inv_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
@@ -124,7 +136,8 @@ struct PolyNtt {
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
                 const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
-                const double w = tw[(1u << s) + blk];
+                // lo >= LL: the lane's high part is empty, the index depends on the register only
+                const double w = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)(m >> (bit + 1))] : tw.lane[(1u << s) + blk];
                 const double u = x[m], v = x[m + hm];
                 x[m] = u + v;
                 x[m + hm] = fp_mulmod(u - v, w);
@@ -138,7 +151,7 @@ struct PolyNtt {
     // `before_last` runs right before the butterflies of the last group: the place to issue global loads whose
     // results are wanted when the transform ends (one group of butterflies ~ one L2 round trip)
     template <int G, class Hook>
-    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw, Hook &&before_last) {
+    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         if constexpr (G + 1 == GROUPS) before_last();
         fwd_group<G>(x, t, tw);
         if constexpr (G + 1 < GROUPS) {
@@ -151,7 +164,7 @@ struct PolyNtt {
         }
     }
     template <int G>
-    __device__ static __forceinline__ void inv_from(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+    __device__ static __forceinline__ void inv_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inv_group<G>(x, t, tw);
         if constexpr (G > 0) {
             double *buf = xc.next();
@@ -165,15 +178,15 @@ struct PolyNtt {
 
     // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
     // (last-group layout, |x| < 9.3 q)
-    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         fwd_from<0>(x, xc, t, tw, NoHook{});
     }
     template <class Hook>
-    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const double *tw, Hook &&before_last) {
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         fwd_from<0>(x, xc, t, tw, before_last);
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q)
-    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const double *tw) {
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inv_from<GROUPS - 1>(x, xc, t, tw);
     }
 
