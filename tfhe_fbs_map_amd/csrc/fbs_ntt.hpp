@@ -93,26 +93,40 @@ struct PolyNtt {
         }
     };
 
-    // Cooley-Tukey stages of group G on registers
+    // distinct twiddles of stage s for this lane: one per block of registers the stage pairs up, j = m >> (bit + 1)
+    template <int G>
+    __device__ static __forceinline__ void load_stage(int s, uint32_t t, const Twiddles &tw, double (&w)[E / 2]) {
+        constexpr int lo = lo_of(G);
+        const int bit = LOGN - 1 - s - lo;     // register-index bit paired by this stage
+        const int sh = lo + LOGE - LOGN + s;   // how far the lane's high part reaches into the block id
+        const uint32_t hi_part = t >> lo;
+#pragma unroll
+        for (int j = 0; j < E / 2; j++) {
+            if (j >= (E >> (bit + 1))) continue;
+            // lo >= LL: the lane's high part is empty, the index depends on the register only
+            w[j] = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)j] : tw.lane[(1u << s) + ((hi_part << sh) | (uint32_t)j)];
+        }
+    }
+
+    // Cooley-Tukey stages of group G on registers.  The twiddles of a stage are requested before the butterflies of
+    // the stage before it, so their (LDS or scalar-cache) latency hides behind arithmetic.
     template <int G>
     __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
-        const uint32_t hi_part = t >> lo;
+        double w[LOGE + 1][E / 2];
+        load_stage<G>(s_begin, t, tw, w[0]);
 #pragma unroll
         for (int s = s_begin; s < s_end; s++) {
             const int bit = LOGN - 1 - s - lo;   // register-index bit paired by this stage
             const int hm = 1 << bit;
-            const int sh = lo + LOGE - LOGN + s;  // how far the lane's high part reaches into the block id
+            if (s + 1 < s_end) load_stage<G>(s + 1, t, tw, w[s + 1 - s_begin]);
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
-                const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
-                // lo >= LL: the lane's high part is empty, the index depends on the register only
-                const double w = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)(m >> (bit + 1))] : tw.lane[(1u << s) + blk];
                 const double u = x[m];
-                const double v = fp_mulmod(x[m + hm], w);
+                const double v = fp_mulmod(x[m + hm], w[s - s_begin][m >> (bit + 1)]);
                 x[m] = u + v;
                 x[m + hm] = u - v;
             }
@@ -124,23 +138,21 @@ struct PolyNtt {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
-        const uint32_t hi_part = t >> lo;
+        double w[LOGE + 1][E / 2];
+        load_stage<G>(s_end - 1, t, tw, w[s_end - 1 - s_begin]);
 #pragma unroll
         for (int m = 0; m < E; m++) x[m] = fp_center(x[m]);
 #pragma unroll
         for (int s = s_end - 1; s >= s_begin; s--) {
             const int bit = LOGN - 1 - s - lo;
             const int hm = 1 << bit;
-            const int sh = lo + LOGE - LOGN + s;
+            if (s > s_begin) load_stage<G>(s - 1, t, tw, w[s - 1 - s_begin]);
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
-                const uint32_t blk = (hi_part << sh) | (uint32_t)(m >> (bit + 1));
-                // lo >= LL: the lane's high part is empty, the index depends on the register only
-                const double w = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)(m >> (bit + 1))] : tw.lane[(1u << s) + blk];
                 const double u = x[m], v = x[m + hm];
                 x[m] = u + v;
-                x[m + hm] = fp_mulmod(u - v, w);
+                x[m + hm] = fp_mulmod(u - v, w[s - s_begin][m >> (bit + 1)]);
             }
         }
     }
