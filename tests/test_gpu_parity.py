@@ -81,6 +81,24 @@ def test_bootstrap_bit_exact_all_sizes(nat, toy_params, log_n):
     assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(t) for t in MODES]))
 
 
+@pytest.mark.parametrize("l,beta,t,gamma", [(1, 8, 8, 2), (2, 8, 4, 4), (2, 12, 3, 5), (3, 7, 16, 1), (4, 6, 2, 6), (5, 4, 8, 3),
+                                            (6, 5, 1, 6), (1, 20, 31, 1), (10, 3, 5, 5), (2, 15, 8, 2), (1, 31, 8, 2)])
+def test_bootstrap_bit_exact_all_decompositions(nat, toy_params, l, beta, t, gamma):
+    """Gadget shapes other than the default: digit widths from 3 to 20 bits (balanced digits with carries through
+    every level), 1 to 10 levels, key-switch bases from 2 to 2^6 -- ciphertexts identical to the oracle's.  Not every
+    shape leaves room for the message (a 1-level 8-bit gadget is pure rounding noise); parity does not care."""
+    prm = toy_params.replace(l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=gamma)
+    ctx, o = nat.Context(prm, seed=9), orc.Oracle(prm, seed=9)
+    msgs = np.concatenate([np.arange(len(tb)) for tb in MODES])
+    ids = np.concatenate([np.full(len(tb), i) for i, tb in enumerate(MODES)]).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=21)
+    got = ctx.bootstrap_batch(ctx.tvset(MODES), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, MODES, ids)
+    assert np.array_equal(got, ref)
+    if l * beta >= 20 and beta <= 15 and t * gamma >= 16:
+        assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(tb) for tb in MODES]))
+
+
 def test_bootstrap_bit_exact_p1024(p1024_pair):
     ctx, o = p1024_pair
     rng = np.random.default_rng(42)
