@@ -71,7 +71,8 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int LOGN, int LL>
+// SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double
+template <int LOGN, int LL, bool SMALL_DIGITS>
 __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = PolyNtt<LOGN, LL>;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             // asking for more ahead of time (all of it, or the partner's polynomial too) spills and loses again.
             constexpr int EARLY = E / 4;
             double2 ko[E / 2];
-            W::forward(x, xc, t, twf, [&] {
+            W::template forward<SMALL_DIGITS>(x, xc, t, twf, [&] {
 #pragma unroll
                 for (int m = 0; m < EARLY; m++) ko[m] = k_own[m * LANES + t];
             });
@@ -308,7 +309,10 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     switch (p.log_n_poly) {
 #define X(L)                                                                                                           \
     case L:                                                                                                            \
-        hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L)>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a);  \
+        if (p.beta_bsk <= 9)                                                                                           \
+            hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), true>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a);  \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), false>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a); \
         break;
         FBS_FOR_EACH_SHAPE(X)
 #undef X

@@ -110,7 +110,9 @@ struct PolyNtt {
 
     // Cooley-Tukey stages of group G on registers.  The twiddles of a stage are requested before the butterflies of
     // the stage before it, so their (LDS or scalar-cache) latency hides behind arithmetic.
-    template <int G>
+    // SMALL: the inputs of the transform are below 2^8 in magnitude (gadget digits), so the products of the very first
+    // stage are exact without the FMA remainder
+    template <int G, bool SMALL>
     __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
@@ -126,7 +128,8 @@ struct PolyNtt {
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
                 const double u = x[m];
-                const double v = fp_mulmod(x[m + hm], w[s - s_begin][m >> (bit + 1)]);
+                const double wv = w[s - s_begin][m >> (bit + 1)];
+                const double v = (SMALL && s == 0) ? fp_mulmod_exact(x[m + hm], wv) : fp_mulmod(x[m + hm], wv);
                 x[m] = u + v;
                 x[m + hm] = u - v;
             }
@@ -162,17 +165,17 @@ struct PolyNtt {
     };
     // `before_last` runs right before the butterflies of the last group: the place to issue global loads whose
     // results are wanted when the transform ends (one group of butterflies ~ one L2 round trip)
-    template <int G, class Hook>
+    template <int G, bool SMALL, class Hook>
     __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         if constexpr (G + 1 == GROUPS) before_last();
-        fwd_group<G>(x, t, tw);
+        fwd_group<G, SMALL>(x, t, tw);
         if constexpr (G + 1 < GROUPS) {
             double *buf = xc.next();
             if constexpr (LL == 6) sync();
             store_group<G>(buf, t, x);
             sync();
             load_group<G + 1>(buf, t, x);
-            fwd_from<G + 1>(x, xc, t, tw, before_last);
+            fwd_from<G + 1, SMALL>(x, xc, t, tw, before_last);
         }
     }
     template <int G>
@@ -191,11 +194,12 @@ struct PolyNtt {
     // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
     // (last-group layout, |x| < 9.3 q)
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
-        fwd_from<0>(x, xc, t, tw, NoHook{});
+        fwd_from<0, false>(x, xc, t, tw, NoHook{});
     }
-    template <class Hook>
+    // the same for inputs below 2^8 in magnitude when SMALL is set
+    template <bool SMALL, class Hook>
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
-        fwd_from<0>(x, xc, t, tw, before_last);
+        fwd_from<0, SMALL>(x, xc, t, tw, before_last);
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q)
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
