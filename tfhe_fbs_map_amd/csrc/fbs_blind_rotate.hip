@@ -17,6 +17,7 @@
 #include "fbs_gate.hpp"
 #include "fbs_internal.hpp"
 #include "fbs_ntt.hpp"
+#include "fbs_ntt_split.hpp"
 
 namespace fbs {
 
@@ -34,7 +35,7 @@ struct BrArgs {
 template <int LOGN, int LL>
 __global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__restrict__ src, double *__restrict__ dst,
                                                            const double *__restrict__ tw_fwd, double n_inv, size_t polys) {
-    using W = PolyNtt<LOGN, LL>;
+    using W = typename NttFor<LOGN, LL>::type;
     __shared__ double lds[2 * W::N];
     const uint32_t t = threadIdx.x;
     typename W::Xchg xc{lds, 0};
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__res
 template <int LOGN, int LL>
 __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const uint64_t *b, uint64_t *c, const double *tw_fwd,
                                                      const double *tw_inv, double n_inv) {
-    using W = PolyNtt<LOGN, LL>;
+    using W = typename NttFor<LOGN, LL>::type;
     __shared__ double lds[2 * W::N];
     const uint32_t t = threadIdx.x;
     typename W::Xchg xc{lds, 0};
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 // SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double
 template <int LOGN, int LL, bool SMALL_DIGITS>
 __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
-    using W = PolyNtt<LOGN, LL>;
+    using W = typename NttFor<LOGN, LL>::type;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds[2 * 2 * N];             // [component][ping-pong][N]
     const uint32_t comp = threadIdx.x >> LL;      // GLWE component owned by this thread: 0 = mask, 1 = body

@@ -1,0 +1,225 @@
+// Negacyclic NTT of one polynomial held by ONE wavefront with 16 coefficients per lane, organised so that the wave
+// hides its own LDS latency.
+//
+// After the first Cooley-Tukey stage (registers m and m+8) the polynomial falls apart into two independent
+// half-size transforms: registers 0..7 ("half 0") and registers 8..15 ("half 1").  Each half then runs the schedule of
+// fbs_ntt.hpp with 8 coefficients per lane -- groups of 3 butterfly stages in registers, an exchange through LDS
+// between groups -- but the two halves are issued OUT OF PHASE: while the reads of one half's exchange are in flight
+// the other half computes.  Same arithmetic, same twiddle table (the half rooted at node 2+h of the twiddle tree:
+// stage s' of half h uses tw[((2+h) << s') + block]), one more exchange per half (3 instead of 2, each half as wide),
+// no extra registers: a half's registers hold either the values it is about to store or the ones it just asked for.
+//
+// Interface and conventions are those of PolyNtt (fbs_ntt.hpp): forward = lazy CT, natural order in (register m of
+// lane t = coefficient t + 64 m), inverse = GS with centring per group, 1/N folded into the key, evaluation order
+// defined by "whatever forward() leaves in register m of lane t" -- the key transform uses the same code.
+#pragma once
+#include "fbs_ntt.hpp"
+
+namespace fbs {
+
+template <int LOGN, int LL>
+struct SplitNtt {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LANES = 1 << LL;
+    static constexpr int E = N / LANES;
+    static constexpr int EH = E / 2;           // registers per half
+    static constexpr int LOGM = LOGN - 1;      // a half is a transform of size N/2 ...
+    static constexpr int LOGEH = 3;            // ... with 3 index bits in registers
+    static constexpr int GROUPS = LOGM / LOGEH;
+    static_assert(LL == 6 && E == 16 && LOGM % LOGEH == 0, "one wave, 16 coefficients per lane");
+    using Base = PolyNtt<LOGN, LL>;
+    using Xchg = typename Base::Xchg;
+
+    __device__ static __forceinline__ void sync() { Base::sync(); }
+    __host__ __device__ static constexpr uint32_t key_word(uint32_t t, int m) { return Base::key_word(t, m); }
+    // input / output layout of the coefficient domain: register m of lane t = coefficient t + LANES * m
+    template <int G>
+    __device__ static __forceinline__ uint32_t index_of(uint32_t t, int m) {
+        static_assert(G == 0, "only the coefficient-domain layout is public");
+        return t + (uint32_t)LANES * (uint32_t)m;
+    }
+
+    // ---- one half: local index i (LOGM bits), local stage s' = parent stage - 1 --------------------------------
+    __host__ __device__ static constexpr int lo_of(int g) { return LOGM - (g + 1) * LOGEH; }
+    __device__ static __forceinline__ uint32_t phys(uint32_t i) { return i ^ ((i >> 4) & 31u); }
+    template <int G>
+    __device__ static __forceinline__ uint32_t local_index(uint32_t t, int r) {
+        constexpr int lo = lo_of(G);
+        return ((t >> lo) << (lo + LOGEH)) | ((uint32_t)r << lo) | (t & ((1u << lo) - 1u));
+    }
+    template <int G, int OFF>
+    __device__ static __forceinline__ void store_half(double *buf, uint32_t t, const double (&x)[E]) {
+        const uint32_t base = phys(local_index<G>(t, 0));
+#pragma unroll
+        for (int r = 0; r < EH; r++) buf[base ^ phys(local_index<G>(0, r))] = x[OFF + r];   // phys is XOR-linear
+    }
+    template <int G, int OFF>
+    __device__ static __forceinline__ void load_half(const double *buf, uint32_t t, double (&x)[E]) {
+        const uint32_t base = phys(local_index<G>(t, 0));
+#pragma unroll
+        for (int r = 0; r < EH; r++) x[OFF + r] = buf[base ^ phys(local_index<G>(0, r))];
+    }
+    // All twiddles of group G of half H for this lane: stage k of the group pairs blocks of 2^(LOGEH-k) registers and
+    // needs one twiddle per block.  They are requested by the CALLER, right behind the exchange that leads into the
+    // group and ahead of the other half's work: LDS answers a wave in order, so a request issued later would make
+    // its consumer wait for everything the other half has in flight.
+    struct GroupTw {
+        double w[LOGEH][EH / 2];
+    };
+    template <int G, int H>
+    __device__ static __forceinline__ void load_twiddles(uint32_t t, const Twiddles &tw, GroupTw &g) {
+        constexpr int lo = lo_of(G);
+        const uint32_t hi_part = t >> lo;
+#pragma unroll
+        for (int k = 0; k < LOGEH; k++) {
+            const int s = G * LOGEH + k;
+            const int bit = LOGM - 1 - s - lo;
+            const int sh = lo + LOGEH - LOGM + s;
+            const uint32_t root = (uint32_t)(2 + H) << s;
+#pragma unroll
+            for (int j = 0; j < EH / 2; j++) {
+                if (j >= (EH >> (bit + 1))) continue;
+                // lo >= LL: no lane bit reaches the block index -- the twiddle is wave-uniform (scalar cache, SGPRs)
+                g.w[k][j] = lo >= LL ? tw.uniform[root + (uint32_t)j] : tw.lane[root + ((hi_part << sh) | (uint32_t)j)];
+            }
+        }
+    }
+    template <int G, int H>
+    __device__ static __forceinline__ void fwd_group(double (&x)[E], const GroupTw &g) {
+        constexpr int lo = lo_of(G), OFF = H * EH;
+#pragma unroll
+        for (int k = 0; k < LOGEH; k++) {
+            const int bit = LOGM - 1 - (G * LOGEH + k) - lo, hm = 1 << bit;
+#pragma unroll
+            for (int r = 0; r < EH; r++) {
+                if (r & hm) continue;
+                const double u = x[OFF + r];
+                const double v = fp_mulmod(x[OFF + r + hm], g.w[k][r >> (bit + 1)]);
+                x[OFF + r] = u + v;
+                x[OFF + r + hm] = u - v;
+            }
+        }
+    }
+    template <int G, int H>
+    __device__ static __forceinline__ void inv_group(double (&x)[E], const GroupTw &g) {
+        constexpr int lo = lo_of(G), OFF = H * EH;
+#pragma unroll
+        for (int r = 0; r < EH; r++) x[OFF + r] = fp_center(x[OFF + r]);
+#pragma unroll
+        for (int k = LOGEH - 1; k >= 0; k--) {
+            const int bit = LOGM - 1 - (G * LOGEH + k) - lo, hm = 1 << bit;
+#pragma unroll
+            for (int r = 0; r < EH; r++) {
+                if (r & hm) continue;
+                const double u = x[OFF + r], v = x[OFF + r + hm];
+                x[OFF + r] = u + v;
+                x[OFF + r + hm] = fp_mulmod(u - v, g.w[k][r >> (bit + 1)]);
+            }
+        }
+    }
+    // registers -> LDS -> registers of the next group's layout; the reads are only ISSUED here
+    template <int FROM, int TO, int H>
+    __device__ static __forceinline__ void exchange(double (&x)[E], double *region, uint32_t t) {
+        sync();   // the stores stay behind every earlier read of this region
+        store_half<FROM, H * EH>(region, t, x);
+        sync();
+        load_half<TO, H * EH>(region, t, x);
+    }
+
+    // The requests just issued must leave NOW: left to itself the scheduler sinks them below the other half's
+    // arithmetic (shorter live ranges), which is exactly the latency this schedule exists to hide.
+    __device__ static __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
+
+    // SMALL: |x| < 2^8 on entry (gadget digits): the products of the first stage are exact in one multiply
+    template <bool SMALL, class Hook>
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
+        double *half0 = xc.next(), *half1 = half0 + N / 2;
+        {
+            const double w0 = tw.uniform[1];
+#pragma unroll
+            for (int r = 0; r < EH; r++) {
+                const double u = x[r];
+                const double v = SMALL ? fp_mulmod_exact(x[r + EH], w0) : fp_mulmod(x[r + EH], w0);
+                x[r] = u + v;
+                x[r + EH] = u - v;
+            }
+        }
+        static_assert(GROUPS == 3, "written out for three groups per half");
+        GroupTw ta, tb;
+        load_twiddles<0, 0>(t, tw, ta);
+        load_twiddles<0, 1>(t, tw, tb);
+        fwd_group<0, 0>(x, ta);
+        exchange<0, 1, 0>(x, half0, t);
+        load_twiddles<1, 0>(t, tw, ta);
+        pin();
+        fwd_group<0, 1>(x, tb);
+        exchange<0, 1, 1>(x, half1, t);
+        load_twiddles<1, 1>(t, tw, tb);
+        pin();
+        fwd_group<1, 0>(x, ta);
+        exchange<1, 2, 0>(x, half0, t);
+        load_twiddles<2, 0>(t, tw, ta);
+        pin();
+        fwd_group<1, 1>(x, tb);
+        exchange<1, 2, 1>(x, half1, t);
+        load_twiddles<2, 1>(t, tw, tb);
+        pin();
+        before_last();
+        fwd_group<2, 0>(x, ta);
+        fwd_group<2, 1>(x, tb);
+    }
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
+        forward<false>(x, xc, t, tw, NoHook{});
+    }
+    // evaluations (|x| < 2^52) -> N * coefficients (|x| <= 8 q)
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
+        double *half0 = xc.next(), *half1 = half0 + N / 2;
+        GroupTw ta, tb, t0a, t0b;
+        load_twiddles<2, 0>(t, tw, ta);
+        load_twiddles<2, 1>(t, tw, tb);
+        // the last groups' twiddles are wave-uniform: scalar loads share the LDS counter and return out of order, so
+        // they are requested here, where nothing else is in flight
+        load_twiddles<0, 0>(t, tw, t0a);
+        load_twiddles<0, 1>(t, tw, t0b);
+        const double w0 = tw.uniform[1];
+        inv_group<2, 0>(x, ta);
+        exchange<2, 1, 0>(x, half0, t);
+        load_twiddles<1, 0>(t, tw, ta);
+        pin();
+        inv_group<2, 1>(x, tb);
+        exchange<2, 1, 1>(x, half1, t);
+        load_twiddles<1, 1>(t, tw, tb);
+        pin();
+        inv_group<1, 0>(x, ta);
+        exchange<1, 0, 0>(x, half0, t);
+        pin();
+        inv_group<1, 1>(x, tb);
+        exchange<1, 0, 1>(x, half1, t);
+        pin();
+        inv_group<0, 0>(x, t0a);
+        inv_group<0, 1>(x, t0b);
+        // last Gentleman-Sande stage joins the halves: inputs <= 4 q each, outputs <= 8 q and < 0.75 q
+#pragma unroll
+        for (int r = 0; r < EH; r++) {
+            const double u = x[r], v = x[r + EH];
+            x[r] = u + v;
+            x[r + EH] = fp_mulmod(u - v, w0);
+        }
+    }
+};
+
+// the transform used for a shape: the split schedule where a wave holds a whole polynomial at 16 coefficients per lane
+template <int LOGN, int LL, bool SPLIT = (LL == 6 && LOGN - LL == 4)>
+struct NttFor {
+    using type = PolyNtt<LOGN, LL>;
+};
+template <int LOGN, int LL>
+struct NttFor<LOGN, LL, true> {
+    using type = SplitNtt<LOGN, LL>;
+};
+
+}  // namespace fbs
