@@ -98,7 +98,8 @@ void fbs_tvset_destroy(fbs_tvset *tv);
 int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_in, const uint32_t *table_ids,
                         size_t count, uint64_t *cts_out);
 /* same on device-resident buffers, asynchronous on `stream` (a hipStream_t; NULL = the
- * context's own stream).  d_table_ids is a device array of `count` uint32. */
+ * context's own stream).  d_table_ids is a device array of `count` uint32; being device
+ * memory it cannot be checked by the host: an id >= the set's size selects table 0. */
 int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_cts_in,
                             const uint32_t *d_table_ids, size_t count, uint64_t *d_cts_out, void *stream);
 

@@ -157,6 +157,24 @@ def test_errors_are_codes_not_crashes(nat, toy_pair):
     assert e.value.code == -3
 
 
+def test_device_side_table_ids_cannot_read_out_of_bounds(toy_pair):
+    """The device-buffer entry point cannot validate ids on the host; a wild id selects table 0 (include/fbs_exec.h)."""
+    import torch
+    ctx, _ = toy_pair
+    tables = [[0, 1, 1, 0, 1, 0, 0], [1, 0, 0, 1, 0, 1, 1]]
+    tv = ctx.tvset(tables)
+    msgs = np.arange(6) % 7
+    cts = ctx.encrypt(msgs, nonce0=50)
+    ids = np.array([0, 1, 2, 1000, 0xFFFFFFFF, 1], np.uint32)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), len(msgs), d_out.data_ptr())
+    ctx.sync()
+    got = ctx.decrypt(d_out.cpu().numpy().view(np.uint64))
+    assert list(got) == [tables[i if i < 2 else 0][m] for i, m in zip(ids.tolist(), msgs)]
+
+
 def test_full_batch_properties_p1024(p1024_pair):
     """BASELINE config 2 at full size (1024 independent FBS, 16 tables): decrypt == table lookup for every
     sample, two runs are bit-identical, and a permuted batch gives the permuted result."""

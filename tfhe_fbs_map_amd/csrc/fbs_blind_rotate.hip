@@ -28,7 +28,7 @@ struct BrArgs {
     const double *tw_fwd, *tw_inv;
     const uint64_t *tvs;     // [tables][N]
     const uint64_t *post;    // [tables]
-    uint32_t n, l, beta, ct_words;
+    uint32_t n, l, beta, ct_words, n_tables;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 
     const size_t f = blockIdx.x;
     const size_t gate = f / a.gv.s_count;
-    const uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    // ids that arrive in device memory cannot be validated by the host: an id past the set reads table 0, never past
+    // the end of the buffer
+    uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    if (table >= a.n_tables) table = 0;
     const uint32_t *ms = a.ms + f * (a.n + 1);
     const uint64_t *tv = a.tvs + (size_t)table * N;
     const uint32_t rows = 2 * a.l;
@@ -301,6 +304,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     a.l = p.l_bsk;
     a.beta = p.beta_bsk;
     a.ct_words = ctx->D + 1;
+    a.n_tables = std::max(1u, tv->n_tables);
     const size_t count = (size_t)gv.n_gates * gv.s_count;
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");
