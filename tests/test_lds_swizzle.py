@@ -1,0 +1,39 @@
+"""Bank-conflict check of the LDS address swizzle of the split transform (csrc/fbs_ntt_split.hpp `phys`), by
+enumeration with the gfx950 banking rules of MI355X_MICROARCH.md (8-byte reads: two 32-lane groups over 64 four-byte
+banks; 8-byte writes: four 16-lane groups over 32 banks).  Pure host arithmetic: the formula is restated here and
+compared with the header's text so the two cannot drift apart."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def phys(i):
+    return i ^ ((i >> 4) & 7) ^ (((i >> 6) & 3) << 3)
+
+
+def local_index(lo, t, r):
+    return ((t >> lo) << (lo + 3)) | (r << lo) | (t & ((1 << lo) - 1))
+
+
+def test_header_uses_this_formula():
+    text = open(os.path.join(ROOT, "tfhe_fbs_map_amd", "csrc", "fbs_ntt_split.hpp")).read()
+    m = re.search(r"uint32_t phys\(uint32_t i\) \{ return (.*?); \}", text)
+    assert m and m.group(1).replace("u", "") == "i ^ ((i >> 4) & 7) ^ (((i >> 6) & 3) << 3)"
+
+
+def test_swizzle_is_a_permutation_and_xor_linear():
+    assert sorted(phys(i) for i in range(512)) == list(range(512))
+    for a in (1, 8, 64, 77, 300, 511):
+        for b in (2, 16, 128, 255, 448):
+            assert phys(a ^ b) == phys(a) ^ phys(b)
+
+
+def test_every_exchange_pattern_is_conflict_free():
+    for lo in (6, 3, 0):                      # the three register/lane layouts of a half transform
+        for r in range(8):
+            words = [phys(local_index(lo, t, r)) for t in range(64)]
+            for g in range(2):                # ds_read_b64: 32 lanes share 64 banks = 32 eight-byte positions
+                assert len({w % 32 for w in words[32 * g:32 * g + 32]}) == 32, (lo, r, "read")
+            for g in range(4):                # ds_write_b64: 16 lanes share 32 banks = 16 eight-byte positions
+                assert len({w % 16 for w in words[16 * g:16 * g + 16]}) == 16, (lo, r, "write")

@@ -41,7 +41,11 @@ struct SplitNtt {
 
     // ---- one half: local index i (LOGM bits), local stage s' = parent stage - 1 --------------------------------
     __host__ __device__ static constexpr int lo_of(int g) { return LOGM - (g + 1) * LOGEH; }
-    __device__ static __forceinline__ uint32_t phys(uint32_t i) { return i ^ ((i >> 4) & 31u); }
+    // LDS word of local index i.  gfx950 banks 8-byte reads per 32 lanes over 32 word positions and 8-byte writes per
+    // 16 lanes over 16; the three layouts walk the lanes through index bits {0..5}, {0..2, 6..8} and {3..8}.  XOR-ing
+    // bits 4..6 into 0..2, bit 6 into 3 and bit 7 into 4 makes every one of those walks a bijection on the bank bits
+    // (checked exhaustively in tests/test_lds_swizzle.py): no bank conflicts in any exchange.
+    __device__ static __forceinline__ uint32_t phys(uint32_t i) { return i ^ ((i >> 4) & 7u) ^ (((i >> 6) & 3u) << 3); }
     template <int G>
     __device__ static __forceinline__ uint32_t local_index(uint32_t t, int r) {
         constexpr int lo = lo_of(G);
