@@ -139,6 +139,22 @@ def test_empty_and_ragged_batches(toy_pair):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("count", [257, 301, 512])
+def test_batches_that_run_two_bootstraps_per_workgroup(toy_pair, count):
+    """Between one and two bootstraps per CU (256 CUs) the launcher pairs bootstraps in four-wave workgroups; an odd
+    count leaves a half-empty workgroup at the end.  Rotation amounts of 0 (a skipped step in one bootstrap of a pair
+    only) occur many times in a batch this size."""
+    ctx, o = toy_pair
+    rng = np.random.default_rng(count)
+    tables = [[0, 1, 1, 0, 1, 0, 0], [0, 1, 2, 3, 2, 1, 0]]
+    msgs = rng.integers(0, 7, count)
+    ids = rng.integers(0, 2, count).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=9000)
+    got = ctx.bootstrap_batch(ctx.tvset(tables), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, tables, ids)
+    assert np.array_equal(got, ref)
+
+
 def test_errors_are_codes_not_crashes(nat, toy_pair):
     ctx, _ = toy_pair
     with pytest.raises(nat.FbsError) as e:

@@ -29,6 +29,7 @@ struct BrArgs {
     const uint64_t *tvs;     // [tables][N]
     const uint64_t *post;    // [tables]
     uint32_t n, l, beta, ct_words, n_tables;
+    size_t count;            // bootstraps in this launch
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -73,13 +74,19 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 
 // ---------------------------------------------------------------------------------------------
 // SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double
-template <int LOGN, int LL, bool SMALL_DIGITS>
-__global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
+// FPW: bootstraps per workgroup.  The hardware deals the waves of a workgroup round the four SIMDs of a CU but starts
+// every workgroup at the same SIMD often enough that two-wave workgroups pile up on two SIMDs while the other two
+// idle whenever a CU holds fewer than four of them (measured: 512 bootstraps took 9.7 ms, 256 took 5.7 ms); four-wave
+// workgroups (two bootstraps) always cover all four SIMDs.
+template <int LOGN, int LL, bool SMALL_DIGITS, int FPW>
+__global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = typename NttFor<LOGN, LL>::type;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
-    __shared__ double lds[2 * 2 * N];             // [component][ping-pong][N]
-    const uint32_t comp = threadIdx.x >> LL;      // GLWE component owned by this thread: 0 = mask, 1 = body
+    __shared__ double lds_all[FPW * 2 * 2 * N];   // [bootstrap][component][ping-pong][N]
+    const uint32_t sub = threadIdx.x >> (LL + 1);          // which bootstrap of the workgroup
+    const uint32_t comp = (threadIdx.x >> LL) & 1u;        // GLWE component owned by this thread: 0 = mask, 1 = body
     const uint32_t t = threadIdx.x & (LANES - 1);
+    double *lds = lds_all + sub * (2 * 2 * N);
     double *mine = lds + comp * 2 * N;
     double *theirs = lds + (comp ^ 1u) * 2 * N;
     typename W::Xchg xc{mine, 0};
@@ -98,7 +105,11 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         twi.lane = lds + 3 * N;
     }
 
-    const size_t f = blockIdx.x;
+    // a workgroup past the end of an odd batch repeats the last bootstrap (its waves must keep meeting the others at
+    // the barriers) and writes nothing
+    const size_t f_want = (size_t)blockIdx.x * FPW + sub;
+    const bool live = f_want < a.count;
+    const size_t f = live ? f_want : a.count - 1;
     const size_t gate = f / a.gv.s_count;
     // ids that arrive in device memory cannot be validated by the host: an id past the set reads table 0, never past
     // the end of the buffer
@@ -132,7 +143,13 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     for (uint32_t i = 0; i < a.n; i++) {
         const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
         r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
-        if (r == 0) continue;   // X^0 * ACC - ACC = 0: nothing to add (uniform over the workgroup)
+        if (r == 0) {           // X^0 * ACC - ACC = 0: nothing to add (uniform over the two waves of a bootstrap)
+            if constexpr (FPW > 1) {   // the other bootstrap of the workgroup still meets its two barriers of this step
+                __syncthreads();
+                __syncthreads();
+            }
+            continue;
+        }
 
         // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
         uint32_t digits[E];
@@ -216,6 +233,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
+    if (!live) return;
     uint64_t *out = gate_out(a.gv, f, a.ct_words);
     if (comp == 0) {
 #pragma unroll
@@ -308,19 +326,34 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const size_t count = (size_t)gv.n_gates * gv.s_count;
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");
-    dim3 grid((unsigned)count);
+    a.count = count;
+    // Two bootstraps per workgroup exactly where two-wave workgroups would double up on half of the SIMDs: between one
+    // and two bootstraps per CU (measured per 1024-coefficient launch: 6.5 ms against 9.8).  Up to one per CU the
+    // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
+    const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
+    dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
+    const bool small_digits = p.beta_bsk <= 9;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
     switch (p.log_n_poly) {
+#define LAUNCH(L, SMALL, FPW)                                                                                          \
+    hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), SMALL, FPW>), grid, dim3((2 << lanes_log2_for(L)) * FPW), 0,     \
+                       stream, a)
 #define X(L)                                                                                                           \
     case L:                                                                                                            \
-        if (p.beta_bsk <= 9)                                                                                           \
-            hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), true>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a);  \
-        else                                                                                                           \
-            hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), false>), grid, dim3(2 << lanes_log2_for(L)), 0, stream, a); \
+        if constexpr (lanes_log2_for(L) == 6) {                                                                        \
+            if (pair && small_digits) LAUNCH(L, true, 2);                                                              \
+            else if (pair) LAUNCH(L, false, 2);                                                                        \
+            else if (small_digits) LAUNCH(L, true, 1);                                                                 \
+            else LAUNCH(L, false, 1);                                                                                  \
+        } else {                                                                                                       \
+            if (small_digits) LAUNCH(L, true, 1);                                                                      \
+            else LAUNCH(L, false, 1);                                                                                  \
+        }                                                                                                              \
         break;
         FBS_FOR_EACH_SHAPE(X)
 #undef X
+#undef LAUNCH
         default: return set_error(ctx, FBS_E_INVALID, "unsupported N");
     }
     prof_end(ctx, 1, stream, e0, e1);
