@@ -214,17 +214,19 @@ struct PolyNtt {
     }
 };
 
-// lanes per polynomial for each supported size (measured on MI355X, 1024-bootstrap batches):
-//   N <= 1024: one wave per polynomial (E = N/64 <= 16): exchanges are wave-private, no barrier inside a transform
-//              (N = 1024: 14.3 ms against 17.7 ms for two waves with E = 8);
-//   N  = 2048: four waves per polynomial, E = 8 (42 ms against 62 ms for two waves with E = 16, which needs
-//              256 VGPRs and leaves two workgroups per CU).
+// lanes per polynomial for each supported size (measured on MI355X, 1024-bootstrap batches): 16 coefficients per lane
+// wherever the polynomial has them.
+//   N <= 1024: one wave per polynomial: exchanges are wave-private, no barrier inside a transform
+//              (N = 1024: 14.3 ms against 17.7 ms for two waves with E = 8, at the time both were measured);
+//   N  = 2048: two waves per polynomial, E = 16, one workgroup barrier per exchange, two exchanges per transform
+//              (34.4 ms against 39.7 ms for four waves with E = 8 and three exchanges; before the kernel's register
+//              diet the E = 16 form spilled and lost, 62 against 42 ms).
 #ifdef FBS_COEFS_PER_LANE_LOG2   // experiments: force 2^k coefficients per lane everywhere it is possible
 __host__ __device__ constexpr int lanes_log2_for(int log_n) {
     return log_n - FBS_COEFS_PER_LANE_LOG2 < 6 ? 6 : log_n - FBS_COEFS_PER_LANE_LOG2;
 }
 #else
-__host__ __device__ constexpr int lanes_log2_for(int log_n) { return log_n <= 10 ? 6 : log_n - 3; }
+__host__ __device__ constexpr int lanes_log2_for(int log_n) { return log_n <= 10 ? 6 : log_n - 4; }
 #endif
 
 }  // namespace fbs
