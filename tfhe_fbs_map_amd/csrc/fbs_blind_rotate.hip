@@ -73,7 +73,8 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 }
 
 // ---------------------------------------------------------------------------------------------
-// SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double
+// SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double, AND
+// l <= 5, so the 2l lazy products (each below 0.75 q) that enter the inverse transform stay below 8 q
 // FPW: bootstraps per workgroup.  The hardware deals the waves of a workgroup round the four SIMDs of a CU but starts
 // every workgroup at the same SIMD often enough that two-wave workgroups pile up on two SIMDs while the other two
 // idle whenever a CU holds fewer than four of them (measured: 512 bootstraps took 9.7 ms, 256 took 5.7 ms); four-wave
@@ -135,9 +136,14 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     // s = 46 - l*beta.  Adding B/2 at every digit position turns the balanced digits (each in [-B/2, B/2), carries
     // included) into plain bit fields:  digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
-    const uint32_t bmask = (1u << a.beta) - 1u, bhalf = 1u << (a.beta - 1);
+    // Flipping the top bit of every field then leaves digit_j in two's complement, ready for a signed bit-field extract.
+    const uint32_t bhalf = 1u << (a.beta - 1);
     double round_offset = 0.5;
-    for (uint32_t j = 0; j < a.l; j++) round_offset += (double)(bhalf << (j * a.beta));
+    uint32_t sign_bits = 0;
+    for (uint32_t j = 0; j < a.l; j++) {
+        round_offset += (double)(bhalf << (j * a.beta));
+        sign_bits |= bhalf << (j * a.beta);
+    }
 
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
     for (uint32_t i = 0; i < a.n; i++) {
@@ -167,7 +173,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 const double w = buf[idx & (N - 1)];
                 const double v = __hiloint2double(__double2hiint(w) + (int)((idx & N) << (31 - LOGN)), __double2loint(w));
                 const double d = fp_canon_near(v - acc[m]);      // (-2q, q) -> [0, q)
-                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset);   // truncation = floor, < 2^(l*beta+1)
+                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;   // truncation = floor, < 2^(l*beta+1)
             }
         }
 
@@ -180,7 +186,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             double x[E];
 #pragma unroll
             for (int m = 0; m < E; m++)
-                x[m] = (double)((int)((digits[m] >> shift) & bmask) - (int)bhalf);   // balanced digit in [-B/2, B/2)
+                x[m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);   // balanced digit in [-B/2, B/2)
             const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
             const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
             const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
@@ -227,7 +233,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         }
 
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
-        W::inverse(own, xc, t, twi);
+        W::template inverse<SMALL_DIGITS>(own, xc, t, twi);
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_canon_near(acc[m] + own[m]);   // |.| <= 9 q
     }
@@ -332,7 +338,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
-    const bool small_digits = p.beta_bsk <= 9;
+    const bool small_digits = p.beta_bsk <= 9 && p.l_bsk <= 5;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
     switch (p.log_n_poly) {

@@ -66,7 +66,10 @@ constexpr double FP_Q = 70368743669761.0;            // q, exactly representable
 constexpr double FP_QINV = 1.0 / 70368743669761.0;   // correctly rounded at compile time
 constexpr double FP_MAGIC = 4503599627370496.0;      // 2^52: x + 2^52 exposes the integer x in the mantissa
 
-// exact residue of x*w in (-0.75q, 0.75q); needs |x| < 2^50 and |w| <= q (twiddles/keys are stored centred)
+// exact residue of x*w in (-0.75q, 0.75q); needs |x| < 2^50 and |w| <= q/2 (twiddles/keys are stored centred).
+// Up to |x| < 2^52 the result is still the exact residue (h - qh*q is an integer below 2^47, so the FMA cannot round;
+// l is the exact low part by construction); only the quotient estimate loosens (error <= |qh| * 2^-52 < 0.3), so the
+// result lies in (-0.8q, 0.8q).
 FBS_D double fp_mulmod(double x, double w) {
     const double h = x * w;
     const double l = __builtin_fma(x, w, -h);

@@ -201,7 +201,9 @@ struct PolyNtt {
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         fwd_from<0, SMALL>(x, xc, t, tw, before_last);
     }
-    // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q)
+    // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q).  BOUNDED (a promise
+    // of |x| <= 8 q) is accepted for interface parity with SplitNtt and not used: four-stage groups need the centring.
+    template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inv_from<GROUPS - 1>(x, xc, t, tw);
     }

@@ -104,11 +104,16 @@ struct SplitNtt {
             }
         }
     }
-    template <int G, int H>
+    // CENTRE = false: the caller promises |x| <= 8 q on entry.  Three Gentleman-Sande stages then feed fp_mulmod at most
+    // 8 * 8 q = 2^52 * (q / 2^46) < 2^52, inside the bound under which it stays exact (fbs_field.hpp; its result is then
+    // below 0.8 q rather than 0.75 q), and leave sums below 64 q < 2^52, which the next group's centring accepts.
+    template <int G, int H, bool CENTRE = true>
     __device__ static __forceinline__ void inv_group(double (&x)[E], const GroupTw &g) {
         constexpr int lo = lo_of(G), OFF = H * EH;
+        if constexpr (CENTRE) {
 #pragma unroll
-        for (int r = 0; r < EH; r++) x[OFF + r] = fp_center(x[OFF + r]);
+            for (int r = 0; r < EH; r++) x[OFF + r] = fp_center(x[OFF + r]);
+        }
 #pragma unroll
         for (int k = LOGEH - 1; k >= 0; k--) {
             const int bit = LOGM - 1 - (G * LOGEH + k) - lo, hm = 1 << bit;
@@ -179,7 +184,8 @@ struct SplitNtt {
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         forward<false>(x, xc, t, tw, NoHook{});
     }
-    // evaluations (|x| < 2^52) -> N * coefficients (|x| <= 8 q)
+    // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q, which spares the first centring pass) -> N * coefficients (|x| <= 8 q)
+    template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         double *half0 = xc.next(), *half1 = half0 + N / 2;
         GroupTw ta, tb, t0a, t0b;
@@ -190,11 +196,11 @@ struct SplitNtt {
         load_twiddles<0, 0>(t, tw, t0a);
         load_twiddles<0, 1>(t, tw, t0b);
         const double w0 = tw.uniform[1];
-        inv_group<2, 0>(x, ta);
+        inv_group<2, 0, !BOUNDED>(x, ta);
         exchange<2, 1, 0>(x, half0, t);
         load_twiddles<1, 0>(t, tw, ta);
         pin();
-        inv_group<2, 1>(x, tb);
+        inv_group<2, 1, !BOUNDED>(x, tb);
         exchange<2, 1, 1>(x, half1, t);
         load_twiddles<1, 1>(t, tw, tb);
         pin();
