@@ -107,7 +107,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_blind_rotate.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="hbm", kernel="k_blind_rotate<10,6,true>", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+        roofline = dict(bound="hbm", kernel="k_blind_rotate<10,6,true,1>", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
                         frac=achieved / HBM_PEAK, traffic=traffic, avg_launch_ms=br_ms, bytes_per_unit=br_bytes_per_fbs,
                         units_per_launch=B, keyswitch_avg_launch_ms=ks_ms,
                         whole_path_bytes_per_fbs=prm.bytes_per_fbs(),
