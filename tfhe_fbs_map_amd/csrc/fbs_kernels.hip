@@ -81,48 +81,54 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     }
 }
 
-// Batches: LANES are ciphertexts (64 per workgroup) and the key words a wave needs are wave-uniform, so they
+// Batches: LANES are ciphertexts (64 or 128 per workgroup) and the key words a wave needs are wave-uniform, so they
 // arrive through the scalar cache (s_load_dwordx16) instead of being re-fetched by every ciphertext tile.  A
-// workgroup owns COLS output columns; its four waves each take a quarter of the kN mask words (more waves in
-// flight to cover the scalar-load latency) and their partial sums meet in LDS.  The rounded mask words are
+// workgroup owns COLS output columns; its waves each take a share of the kN mask words (more waves in flight to
+// cover the scalar-load latency, which is what bounds this kernel) and their partial sums meet in LDS.  The rounded mask words are
 // staged per tile in LDS, transposed on the way in so that both the global read (along the ciphertext row) and
 // the LDS read (along the ciphertexts) are contiguous.
-template <int COLS>
-__global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
-    constexpr int JT = 16;                       // mask words per wave per staging round (16 KB of LDS: 8 workgroups/CU)
-    __shared__ uint32_t tile[4 * JT * 64];       // [slice][j in tile][ciphertext]; reused for the final reduction
-    __shared__ const uint64_t *ct_ptr[64];       // row base of the 64 ciphertexts (the slot lookup costs a 64-bit division)
-    static_assert(4 * JT * 64 >= 3 * COLS * 2 * 64, "reduction scratch must fit in the staging tile");
+// CPL: ciphertexts per lane (every scalar key load then feeds CPL times the multiply-adds); WAVES: waves per workgroup,
+// each taking 1/WAVES of the mask words (more waves in flight per ciphertext tile to cover the scalar-load latency)
+template <int COLS, int CPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
+    constexpr int JT = 64 / WAVES;               // mask words per wave per staging round (tile = 16 KB * CPL of LDS)
+    constexpr int CTS = 64 * CPL;                // ciphertexts per workgroup
+    constexpr int THREADS = 64 * WAVES;
+    __shared__ uint32_t tile[WAVES * JT * CTS];  // [slice][j in tile][ciphertext]; reused for the final reduction
+    __shared__ const uint64_t *ct_ptr[CTS];      // row base of the ciphertexts (the slot lookup costs a 64-bit division)
+    static_assert(WAVES * JT * CTS >= (WAVES / 2) * COLS * 2 * CTS, "reduction scratch must fit in the staging tile");
+    static_assert(WAVES >= 2 && (WAVES & (WAVES - 1)) == 0, "tree reduction over the waves");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const size_t f0 = (size_t)blockIdx.x * 64;
-    const size_t f = f0 + lane;
+    const size_t f0 = (size_t)blockIdx.x * CTS;
     const uint32_t col0 = blockIdx.y * COLS;
     const uint32_t tg = a.t * a.gamma;
     const uint32_t dmask = (1u << a.gamma) - 1u;
-    const uint32_t slice_len = (a.D + 3) / 4;    // mask words per wave
+    const uint32_t slice_len = (a.D + WAVES - 1) / WAVES;    // mask words per wave
 
     // two accumulators per column: digit x low word (one v_mad_u64_u32) and digit x high 14 bits (one 24-bit mad);
     // neither can overflow (dev_supported), and there is no carry to move between registers in the loop
-    uint64_t acc_lo[COLS];
-    uint32_t acc_hi[COLS];
+    uint64_t acc_lo[CPL][COLS];
+    uint32_t acc_hi[CPL][COLS];
 #pragma unroll
-    for (int c = 0; c < COLS; c++) {
-        acc_lo[c] = 0;
-        acc_hi[c] = 0;
-    }
-    if (threadIdx.x < 64) ct_ptr[threadIdx.x] = f < a.count ? gate_in(a.gv, f, a.ct_words) : nullptr;
+    for (int u = 0; u < CPL; u++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            acc_lo[u][c] = 0;
+            acc_hi[u][c] = 0;
+        }
+    for (uint32_t q = threadIdx.x; q < CTS; q += THREADS) ct_ptr[q] = f0 + q < a.count ? gate_in(a.gv, f0 + q, a.ct_words) : nullptr;
 
     for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
         __syncthreads();
-        // 256 threads stage 4 slices x JT words x 64 ciphertexts: consecutive threads read consecutive words
-        for (uint32_t idx = threadIdx.x; idx < 4 * JT * 64; idx += 256) {
-            const uint32_t jj = idx % JT, q = (idx / JT) % 64, sl = idx / (JT * 64);
+        // the workgroup stages WAVES slices x JT words x CTS ciphertexts: consecutive threads read consecutive words
+        for (uint32_t idx = threadIdx.x; idx < WAVES * JT * CTS; idx += THREADS) {
+            const uint32_t jj = idx % JT, q = (idx / JT) % CTS, sl = idx / (JT * CTS);
             const uint32_t j = sl * slice_len + r0 + jj;
             uint32_t v = 0;
             const uint64_t *row = ct_ptr[q];
             if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg);
-            tile[(sl * JT + jj) * 64 + q] = v;
+            tile[(sl * JT + jj) * CTS + q] = v;
         }
         __syncthreads();
         // this wave's mask words of the round.  The key-row address depends only on (wave, jj, v): the compiler keeps
@@ -131,7 +137,9 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
         for (uint32_t jj = 0; jj < JT; jj++) {
             const uint32_t j = wave * slice_len + r0 + jj;
             if (r0 + jj >= slice_len || j >= a.D) break;          // wave-uniform
-            const uint32_t ab = tile[(wave * JT + jj) * 64 + lane];
+            uint32_t ab[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; u++) ab[u] = tile[(wave * JT + jj) * CTS + lane + 64 * u];
             // constant address space: the key is read-only for the life of the kernel and the address is wave-uniform,
             // so these become scalar loads (s_load_dwordx16).  As plain global loads they are 64-lane broadcasts that
             // saturate the vector memory address path (measured: 1.2 ms instead of 0.x ms per 1024-batch).
@@ -139,34 +147,58 @@ __global__ __launch_bounds__(256) void k_keyswitch_lanes(KsArgs a) {
             const const_words krow = (const_words)(uintptr_t)(a.ksk + (size_t)j * a.t * a.stride + col0);
 #pragma unroll 4
             for (uint32_t v = 0; v < a.t; v++) {
-                const uint32_t d = (ab >> (a.gamma * (a.t - 1 - v))) & dmask;
+                uint32_t d[CPL];
+#pragma unroll
+                for (int u = 0; u < CPL; u++) d[u] = (ab[u] >> (a.gamma * (a.t - 1 - v))) & dmask;
 #pragma unroll
                 for (int c = 0; c < COLS; c++) {
                     const uint64_t kw = krow[(size_t)v * a.stride + c];
-                    acc_lo[c] += (uint64_t)d * (uint32_t)kw;
-                    acc_hi[c] += __umul24(d, (uint32_t)(kw >> 32));
+#pragma unroll
+                    for (int u = 0; u < CPL; u++) {
+                        acc_lo[u][c] += (uint64_t)d[u] * (uint32_t)kw;
+                        acc_hi[u][c] += __umul24(d[u], (uint32_t)(kw >> 32));
+                    }
                 }
             }
         }
     }
-    // waves 1..3 park their partial sums; wave 0 adds them up, folds mod q and mod-switches
-    __syncthreads();
+    // the partial sums of the waves meet in LDS, halving the number of waves that still hold one each round;
+    // wave 0 folds mod q and mod-switches
+    uint64_t sum[CPL][COLS];
+#pragma unroll
+    for (int u = 0; u < CPL; u++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) sum[u][c] = acc_lo[u][c] + ((uint64_t)acc_hi[u][c] << 32);
     uint64_t *park = reinterpret_cast<uint64_t *>(tile);
-    if (wave) {
 #pragma unroll
-        for (int c = 0; c < COLS; c++) park[((wave - 1) * COLS + c) * 64 + lane] = acc_lo[c] + ((uint64_t)acc_hi[c] << 32);
+    for (int half = WAVES / 2; half >= 1; half /= 2) {
+        __syncthreads();
+        if (wave >= (uint32_t)half && wave < 2u * half) {
+#pragma unroll
+            for (int u = 0; u < CPL; u++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) park[((wave - half) * COLS + c) * CTS + lane + 64 * u] = sum[u][c];
+        }
+        __syncthreads();
+        if (wave < (uint32_t)half) {
+#pragma unroll
+            for (int u = 0; u < CPL; u++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) sum[u][c] += park[(wave * COLS + c) * CTS + lane + 64 * u];
+        }
     }
-    __syncthreads();
-    if (wave || f >= a.count) return;
-    const uint64_t body = ct_ptr[lane][a.D];
+    if (wave) return;
 #pragma unroll
-    for (int c = 0; c < COLS; c++) {
-        const uint32_t col = col0 + c;
-        if (col > a.n) break;
-        uint64_t sum = acc_lo[c] + ((uint64_t)acc_hi[c] << 32);
+    for (int u = 0; u < CPL; u++) {
+        const size_t f = f0 + lane + 64 * u;
+        if (f >= a.count) continue;
+        const uint64_t body = ct_ptr[lane + 64 * u][a.D];
 #pragma unroll
-        for (int w = 0; w < 3; w++) sum += park[(w * COLS + c) * 64 + lane];
-        a.ms[f * (a.n + 1) + col] = ks_finish(sum, col == a.n ? body : 0, a.log2_2n);
+        for (int c = 0; c < COLS; c++) {
+            const uint32_t col = col0 + c;
+            if (col > a.n) break;
+            a.ms[f * (a.n + 1) + col] = ks_finish(sum[u][c], col == a.n ? body : 0, a.log2_2n);
+        }
     }
 }
 
@@ -253,8 +285,12 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     if (a.count >= 32) {
         // lanes = ciphertexts: pays once a wave is at least half full
         constexpr int COLS = 8;
-        dim3 grid((unsigned)((a.count + 63) / 64), (p.n + 1 + COLS - 1) / COLS);
-        hipLaunchKernelGGL(k_keyswitch_lanes<COLS>, grid, dim3(256), 0, stream, a);
+        // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65
+        const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
+        if (a.count > 64)
+            hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 2, 8>), dim3((unsigned)((a.count + 127) / 128), cols), dim3(512), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 1, 4>), dim3(1, cols), dim3(256), 0, stream, a);
     } else {
         constexpr int FB = 8;
         dim3 grid((unsigned)((a.count + FB - 1) / FB), ctx->ksk_stride / 256);
