@@ -94,9 +94,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
     constexpr int JT = 64 / WAVES;               // mask words per wave per staging round (tile = 16 KB * CPL of LDS)
     constexpr int CTS = 64 * CPL;                // ciphertexts per workgroup
     constexpr int THREADS = 64 * WAVES;
-    __shared__ uint32_t tile[WAVES * JT * CTS];  // [slice][j in tile][ciphertext]; reused for the final reduction
+    constexpr int TILE_WORDS = WAVES * JT * CTS > (WAVES / 2) * COLS * 2 * CTS ? WAVES * JT * CTS : (WAVES / 2) * COLS * 2 * CTS;
+    __shared__ uint32_t tile[TILE_WORDS];        // [slice][j in tile][ciphertext]; reused for the final reduction
     __shared__ const uint64_t *ct_ptr[CTS];      // row base of the ciphertexts (the slot lookup costs a 64-bit division)
-    static_assert(WAVES * JT * CTS >= (WAVES / 2) * COLS * 2 * CTS, "reduction scratch must fit in the staging tile");
     static_assert(WAVES >= 2 && (WAVES & (WAVES - 1)) == 0, "tree reduction over the waves");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -285,7 +285,8 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     if (a.count >= 32) {
         // lanes = ciphertexts: pays once a wave is at least half full
         constexpr int COLS = 8;
-        // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65
+        // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65,
+        // 256 x 8 waves 1.32, 128 x 16 waves 0.86, 256 x 16 waves 1.80
         const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
         if (a.count > 64)
             hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 2, 8>), dim3((unsigned)((a.count + 127) / 128), cols), dim3(512), 0, stream, a);
