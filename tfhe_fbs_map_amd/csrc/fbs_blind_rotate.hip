@@ -221,6 +221,9 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         }
 
         // ---- hand the partner its half of the external product (same ping-pong slot in both regions) ----
+        // (the wave-uniform twiddles of the inverse transform are requested first: scalar loads, in flight across the
+        // two barriers instead of in front of the first butterflies)
+        const typename W::InvUniform inv_uni = W::inverse_uniform(t, twi);
         {
             const uint32_t slot = xc.pp ? xc.stride : 0;
             xc.pp ^= 1u;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         }
 
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
-        W::template inverse<SMALL_DIGITS>(own, xc, t, twi);
+        W::template inverse<SMALL_DIGITS>(own, xc, t, twi, inv_uni);
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_canon_near(acc[m] + own[m]);   // |.| <= 9 q
     }

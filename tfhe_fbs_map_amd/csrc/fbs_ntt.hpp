@@ -203,6 +203,13 @@ struct PolyNtt {
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q).  BOUNDED (a promise
     // of |x| <= 8 q) is accepted for interface parity with SplitNtt and not used: four-stage groups need the centring.
+    // interface parity with SplitNtt (which takes its wave-uniform inverse twiddles from the caller): nothing to carry
+    struct InvUniform {};
+    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t, const Twiddles &) { return {}; }
+    template <bool BOUNDED = false>
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &) {
+        inverse<BOUNDED>(x, xc, t, tw);
+    }
     template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inv_from<GROUPS - 1>(x, xc, t, tw);

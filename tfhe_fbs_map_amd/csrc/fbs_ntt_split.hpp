@@ -185,17 +185,32 @@ struct SplitNtt {
         forward<false>(x, xc, t, tw, NoHook{});
     }
     // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q, which spares the first centring pass) -> N * coefficients (|x| <= 8 q)
+    // The wave-uniform twiddles of the inverse (last group of each half + the joining stage).  Scalar loads share the
+    // LDS counter and return out of order, so whoever waits for one waits for everything in flight: a caller with slack
+    // ahead of the transform (a barrier, say) requests them there with inverse_uniform() and passes them in.
+    struct InvUniform {
+        GroupTw a, b;
+        double w0;
+    };
+    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t t, const Twiddles &tw) {
+        InvUniform u;
+        load_twiddles<0, 0>(t, tw, u.a);
+        load_twiddles<0, 1>(t, tw, u.b);
+        u.w0 = tw.uniform[1];
+        return u;
+    }
     template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
+        inverse<BOUNDED>(x, xc, t, tw, inverse_uniform(t, tw));
+    }
+    template <bool BOUNDED = false>
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &uni) {
         double *half0 = xc.next(), *half1 = half0 + N / 2;
-        GroupTw ta, tb, t0a, t0b;
+        GroupTw ta, tb;
         load_twiddles<2, 0>(t, tw, ta);
         load_twiddles<2, 1>(t, tw, tb);
-        // the last groups' twiddles are wave-uniform: scalar loads share the LDS counter and return out of order, so
-        // they are requested here, where nothing else is in flight
-        load_twiddles<0, 0>(t, tw, t0a);
-        load_twiddles<0, 1>(t, tw, t0b);
-        const double w0 = tw.uniform[1];
+        const GroupTw &t0a = uni.a, &t0b = uni.b;
+        const double w0 = uni.w0;
         inv_group<2, 0, !BOUNDED>(x, ta);
         exchange<2, 1, 0>(x, half0, t);
         load_twiddles<1, 0>(t, tw, ta);
