@@ -113,7 +113,9 @@ def main():
                         whole_path_bytes_per_fbs=prm.bytes_per_fbs(),
                         whole_path_frac=value / world * prm.bytes_per_fbs() / HBM_PEAK,
                         note="achieved/frac are ALGORITHMIC bytes over time; the key stream is served from L2/MALL after first "
-                             "touch (traffic = PMC-measured fabric bytes per launch) and the kernel is VALU (FP64-rate) bound, see DESIGN.md")
+                             "touch (traffic = PMC-measured fabric bytes per launch) and the kernel is bound by FP64 issue: "
+                             "4.8e9 VALU wave-instructions per launch (PMC) against a measured ceiling of one v_fma_f64 per SIMD per "
+                             "4.8-5.0 nominal cycles at two waves per SIMD (profiles/r01/fp64_issue_rate.txt) = 9.7 ms; see DESIGN.md")
         result = dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world,
                       steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
                       higher_is_better=True, scaling="weak", vs_baseline=None,
