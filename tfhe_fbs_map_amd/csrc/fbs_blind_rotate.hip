@@ -171,7 +171,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             for (int m = 0; m < E; m++) {
                 const uint32_t idx = from + (uint32_t)LANES * m;   // < 3N: bit LOGN = sign, bits below = position
                 const double w = buf[idx & (N - 1)];
-                const double v = __hiloint2double(__double2hiint(w) + (int)((idx & N) << (31 - LOGN)), __double2loint(w));
+                const double v = __hiloint2double(__double2hiint(w) ^ (int)((idx << (31 - LOGN)) & 0x80000000u), __double2loint(w));
                 const double d = fp_canon_near(v - acc[m]);      // (-2q, q) -> [0, q)
                 digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;   // truncation = floor, < 2^(l*beta+1)
             }
