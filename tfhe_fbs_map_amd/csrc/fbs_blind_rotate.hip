@@ -1,9 +1,9 @@
 // Blind rotation + sample extraction (the hot kernel), the one-time key transform and a debug product, all on
-// the NTT of fbs_ntt.hpp.  gfx950 only.  Exact modular arithmetic on integer-valued doubles (fbs_field.hpp): the
+// the NTT of fbs_ntt.hpp / fbs_ntt_split.hpp.  gfx950 only.  Exact modular arithmetic on integer-valued doubles (fbs_field.hpp): the
 // FP64 FMA is the machine's widest exact multiplier; no MFMA, no tensor contraction -- every product is an
 // element-wise residue product.
 //
-// One functional bootstrap = one workgroup; GLWE component c (k = 1: mask, body) is owned by LANES lanes, each
+// One functional bootstrap = two waves (or 2 x LANES/64) of a workgroup; GLWE component c (k = 1: mask, body) is owned by LANES lanes, each
 // holding E coefficients of the accumulator in VGPRs.  Per CMUX step: accumulator -> LDS, gather the rotated copy
 // (X^a), subtract, round to l*beta bits; per digit level: balanced digit -> forward NTT -> multiply-accumulate with
 // the two key polynomials of that row (lazy sums); hand the partner component its half through LDS; inverse NTT;
@@ -209,9 +209,6 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 own[2 * j] += fp_mulmod(x[2 * j], ko[j].x);
                 own[2 * j + 1] += fp_mulmod(x[2 * j + 1], ko[j].y);
                 kt[j] = k_oth[j * LANES + t];
-#ifdef FBS_BR_PIN
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
