@@ -511,12 +511,20 @@ static void poly_rotate(const uint64_t *in, uint64_t *out, uint32_t r, uint32_t 
     }
 }
 
-/* signed balanced digits of the closest multiple of q/B^l; out[lv][j] as field elements */
+/* signed balanced digits of the closest multiple of q/B^l; out[lv][j] as field elements.
+ * The rounding treats q as 2^46 (a shift), which scales the value by 2^46/q = 1 + 7.2e-9.  Applied to the canonical
+ * residue in [0, q) that error is always of one sign and adds up coherently through the N/2 key bits (measured: it
+ * dominated the bootstrap noise once l*beta >= 24); applied to the CENTRED residue in (-q/2, q/2] it averages out.
+ * So: centre, round half up to a multiple of 2^s (s = 46 - l*beta), keep the result mod B^l. */
 static void decompose_poly(const orc_ctx *c, const uint64_t *poly, uint64_t *digits /* l*N */) {
     uint32_t N = c->N, l = c->p.l_bsk, beta = c->p.beta_bsk;
     uint64_t B = 1ull << beta, half = B >> 1;
+    const int s = ORC_QBITS - (int)(l * beta);
     for (uint32_t j = 0; j < N; j++) {
-        uint64_t abar = ((poly[j] >> (ORC_QBITS - 1 - l * beta)) + 1) >> 1;
+        int64_t v = poly[j] > ORC_Q / 2 ? (int64_t)poly[j] - (int64_t)ORC_Q : (int64_t)poly[j];
+        int64_t t = v + ((int64_t)1 << (s - 1));
+        int64_t r = t >= 0 ? t >> s : -((-t + ((int64_t)1 << s) - 1) >> s);   /* floor(t / 2^s) */
+        uint64_t abar = (uint64_t)r & ((1ull << (l * beta)) - 1);
         for (int lv = (int)l - 1; lv >= 0; lv--) {
             int64_t dg = (int64_t)(abar & (B - 1));
             abar >>= beta;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     }
 
     // Rounding runs on doubles too (floor(x * 2^-s + c) is exact on integers): abar = (d + 2^(s-1)) >> s with
-    // s = 46 - l*beta.  Adding B/2 at every digit position turns the balanced digits (each in [-B/2, B/2), carries
+    // s = 46 - l*beta, d the centred residue, abar kept mod B^l.  Adding B/2 at every digit position turns the balanced digits (each in [-B/2, B/2), carries
     // included) into plain bit fields:  digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
     // Flipping the top bit of every field then leaves digit_j in two's complement, ready for a signed bit-field extract.
@@ -172,7 +172,9 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 const uint32_t idx = from + (uint32_t)LANES * m;   // < 3N: bit LOGN = sign, bits below = position
                 const double w = buf[idx & (N - 1)];
                 const double v = __hiloint2double(__double2hiint(w) ^ (int)((idx << (31 - LOGN)) & 0x80000000u), __double2loint(w));
-                const double d = fp_canon_near(v - acc[m]);      // (-2q, q) -> [0, q)
+                // centred, not canonical: the rounding below treats q as 2^46, an error proportional to the value --
+                // of one sign on [0, q) (it then adds up coherently through the key bits), symmetric on (-q/2, q/2]
+                const double d = fp_center(v - acc[m]);          // (-2q, q) -> [-q/2, q/2]
                 digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;   // truncation = floor, < 2^(l*beta+1)
             }
         }
