@@ -310,7 +310,7 @@ def test_output_noise_stays_inside_the_box(p1024_pair):
 
 
 def test_noise_model_holds_for_the_n2048_set(nat):
-    """The p = 31 parameter set (N = 2048, l = 4, beta = 6): measured bootstrap output noise against params.variances,
+    """The p = 31 parameter set (N = 2048, l = 3, beta = 8): measured bootstrap output noise against params.variances,
     and every output inside its box."""
     from tfhe_fbs_map_amd.params import params_for, variances
     prm = params_for(31)

@@ -18,10 +18,11 @@ import math
 from ._native import MODULUS, Params
 
 P1024 = Params()                                            # n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2
-# p = 31 needs the wider accumulator, and its linear combinations (norm2 up to ~325) need a finer decomposition:
-# with l*beta = 21 bits the rounding of the decomposition alone (n(1+N/2)/(12 B^2l)) times 325 eats the box
-P2048 = Params(n=630, log_n_poly=11, l_bsk=4, beta_bsk=6)
-
+# p = 31 needs the wider accumulator, and its linear combinations (norm2 up to ~325) need a finer decomposition than
+# P1024's 21 bits: 24 bits.  At the (reduced) key noise of the defaults a wide base costs nothing, so the 24 bits are
+# 3 levels of 8 rather than 4 of 6 (one forward transform less per component and step; same margin in the model
+# below, 6.3 sigma at norm2 = 325).
+P2048 = Params(n=630, log_n_poly=11, l_bsk=3, beta_bsk=8)
 
 def params_for(p: int, norm2: int | None = None) -> Params:
     """Default set for plaintext modulus p: the modulus switch alone (n = 630) leaves about
