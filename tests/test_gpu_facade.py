@@ -158,3 +158,17 @@ def test_command_line_front_end(tmp_path, capsys):
     ins = {name: np.random.randint(0, 2, (16)) for name in rec["harness_inputs"]}
     expect = lut_oracle.eval_fbs_text(rec["fbs"], ins)
     assert line["outputs"] == {k: int(np.sum(v)) for k, v in expect.items()}
+
+
+def test_model_chosen_parameters_evaluate_correctly():
+    """ExecConfig(auto_params=True): the gadget and key-switch shape come from params.choose_params at the program's own
+    (p, norm2); every output of every sample must still decrypt to the reference's cleartext result."""
+    from tfhe_fbs_map_amd import ExecConfig, choose_params, parse_fbs
+    cfg = ExecConfig(auto_params=True)
+    for name, T in (("mul16__search_p15", 200), ("aes_sbox__search_p15", 64), ("adder128__search_p31", 8)):
+        rec = load_fixture(name)
+        ins, expect = subsample(rec, T)
+        env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+        assert_outputs_equal(env.eval(ins, config=cfg), expect)
+    chosen = {c.params.l_bsk for c in cfg._contexts.values()}
+    assert chosen and max(chosen) <= 3          # the model picks a cheaper gadget than the fixed sets at this noise

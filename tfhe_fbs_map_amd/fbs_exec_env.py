@@ -68,12 +68,20 @@ class ExecConfig:
     seed: int = 1
     device: int = 0
     nonce0: int = 0
+    # params=None and auto_params: the cheapest gadget / key-switch shape whose modelled margin at the program's
+    # (p, norm2_linprod) is at least min_margin sigmas (params.choose_params) instead of the fixed default set --
+    # the role of the patched optimizer in the reference's flow (experiments/add_exec_estimates.py:9-16)
+    auto_params: bool = False
+    min_margin: float = 6.0
     _contexts: dict = field(default_factory=dict, repr=False)
 
-    def context_for(self, p):
+    def context_for(self, p, norm2=1):
         from . import _native as nat
-        from .params import params_for
-        prm = (self.params or params_for(p)).replace(p_msg=p)
+        from .params import choose_params, params_for
+        if self.params is None and self.auto_params:
+            prm = choose_params(p, norm2, self.min_margin)
+        else:
+            prm = (self.params or params_for(p)).replace(p_msg=p)
         key = (prm, self.seed, self.device)
         ctx = self._contexts.get(key)
         if ctx is None:
@@ -343,7 +351,7 @@ class LutExecEnv:
         p = cfg.fbs_size or min_fbs_size(low["tables"])
         for t in low["tables"]:
             assert table_is_valid(t, p), "table %s cannot be evaluated by one bootstrap at fbs_size %d" % (t, p)
-        ctx = cfg.context_for(p)
+        ctx = cfg.context_for(p, self.stats()["norm2_linprod"] if cfg.auto_params else 1)
 
         names = low["input_names"]
         cols = [np.asarray(input_values[n]).reshape(-1) for n in names]

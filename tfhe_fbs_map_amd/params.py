@@ -56,3 +56,41 @@ def margin_sigmas(prm: Params, norm2: float = 1.0) -> float:
     v_br, v_ks, v_ms = variances(prm)
     sigma = math.sqrt(norm2 * v_br + v_ks + v_ms)
     return (1.0 / (4.0 * prm.p_msg)) / sigma
+
+
+def bootstrap_cost(prm: Params) -> float:
+    """Relative cost of one functional bootstrap, in the unit the kernels are bound by: n CMUX steps of (k+1)(l+1)
+    transforms of N log N butterflies plus (k+1)^2 l N exact products, and the kN t (n+1) multiply-adds of the key
+    switch weighted by their measured share (5 % of the P1024 step).  The reference ranks parameter sets by the
+    optimizer's `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
+    N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
+    blind = n * ((k + 1) * (l + 1) * N * prm.log_n_poly / 2.0 * 1.14 + (k + 1) ** 2 * l * N)
+    switch = k * N * t * (n + 1)
+    p1024_blind = 630 * (2 * 4 * 1024 * 5 * 1.14 + 4 * 3 * 1024)
+    p1024_switch = 1024 * 8 * 631
+    return 0.95 * blind / p1024_blind + 0.05 * switch / p1024_switch
+
+
+def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, sigma: int | None = None) -> Params:
+    """Cheapest gadget / key-switch shape whose modelled margin at (p, norm2) is at least `min_margin` standard
+    deviations -- what the reference obtains from its patched optimizer for (precision, squared 2-norm)
+    (experiments/add_exec_estimates.py:9-16, experiments/concrete.patch:21-27,66-74).  n and the noise are those of
+    the default sets (`sigma` overrides both standard deviations); N is the smallest power of two whose modulus switch
+    leaves room for p.  Falls back to the shape with the largest margin when none reaches `min_margin`."""
+    base = params_for(p)
+    if sigma is not None:
+        base = base.replace(sigma_lwe=sigma, sigma_glwe=sigma)
+    # conventional shapes only: 2..6 levels of 4..12 bits, key-switch digits of 1..4 bits (the executor itself takes
+    # wider ones; with the reduced default noise the model would happily pick a single 19-bit level)
+    gadgets = [(l, beta) for l in (2, 3, 4, 5, 6) for beta in range(4, 13) if 12 <= l * beta <= 30]
+    switches = [(t, g) for t, g in ((4, 4), (5, 3), (6, 3), (8, 2), (10, 2), (16, 1), (20, 1))
+                if 46 + g + math.log2(t * base.N) <= 63.9]
+    best, best_key = None, None
+    for l, beta in gadgets:
+        for t, g in switches:
+            cand = base.replace(l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=g)
+            m = margin_sigmas(cand, norm2)
+            key = (0, bootstrap_cost(cand), -m) if m >= min_margin else (1, -m, bootstrap_cost(cand))
+            if best_key is None or key < best_key:
+                best, best_key = cand, key
+    return best

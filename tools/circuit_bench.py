@@ -11,7 +11,13 @@ for name, T in (("mul16__search_p15", 1000), ("adder128__search_p15", 1000), ("t
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     low = env.lower()
     ins, expect = subsample(rec, T)
-    ctx = Context(Params(), seed=1)
+    if os.environ.get("AUTO_PARAMS"):          # params.choose_params at the program's (p, norm2) instead of P1024
+        from tfhe_fbs_map_amd import choose_params
+        prm = choose_params(15, env.stats()["norm2_linprod"])
+        print("  chosen: l=%d beta=%d t=%d gamma=%d" % (prm.l_bsk, prm.beta_bsk, prm.t_ksk, prm.gamma_ksk))
+    else:
+        prm = Params()
+    ctx = Context(prm, seed=1)
     tv = ctx.tvset(low["tables"])
     prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
                        low["term_coef"], low["term_src"], low["out_wire"])
