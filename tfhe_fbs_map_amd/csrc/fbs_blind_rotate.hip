@@ -92,8 +92,8 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     double *theirs = lds + (comp ^ 1u) * 2 * N;
     typename W::Xchg xc{mine, 0};
     Twiddles twf(a.tw_fwd, a.tw_fwd), twi(a.tw_inv, a.tw_inv);
-    if constexpr (LL == 6) {
-        // A polynomial that lives in one wave needs no ping-pong buffer; the spare half of each component's region
+    if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) {
+        // One exchange buffer per polynomial (fbs_ntt.hpp); the other half of each component's region
         // holds a twiddle table instead (forward in component 0's, inverse in component 1's), so the per-lane
         // twiddle gathers are LDS reads, not 64-address global loads.
         xc.stride = 0;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         uint32_t digits[E];
         {
             double *buf = xc.next();
-            if constexpr (LL == 6) W::sync();
+            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) W::sync();
             // both the store and the rotated read walk consecutive words across the lanes: no swizzle needed here
 #pragma unroll
             for (int m = 0; m < E; m++) buf[t + (uint32_t)LANES * m] = acc[m];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         {
             const uint32_t slot = xc.pp ? xc.stride : 0;
             xc.pp ^= 1u;
-            if constexpr (LL == 6) __syncthreads();   // wave-private exchanges: the partner may still be inside its own
+            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) __syncthreads();   // one-buffer exchanges: the partner may still be inside its own
 #pragma unroll
             for (int m = 0; m < E; m++) theirs[slot + m * LANES + t] = other[m];
             __syncthreads();

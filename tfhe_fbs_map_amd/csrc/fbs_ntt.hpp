@@ -32,6 +32,12 @@ struct Twiddles {
         : lane(lane_table), uniform((uniform_doubles)(uintptr_t)global_table) {}
 };
 
+// polynomials spread over up to 2^FBS_ONE_BUFFER_MAX_LL lanes exchange through ONE buffer (a second synchronisation
+// per exchange instead of a ping-pong pair), which leaves room for twiddle tables in LDS
+#ifndef FBS_ONE_BUFFER_MAX_LL
+#define FBS_ONE_BUFFER_MAX_LL 7
+#endif
+
 template <int LOGN, int LL>
 struct PolyNtt {
     static constexpr int N = 1 << LOGN;
@@ -171,7 +177,7 @@ struct PolyNtt {
         fwd_group<G, SMALL>(x, t, tw);
         if constexpr (G + 1 < GROUPS) {
             double *buf = xc.next();
-            if constexpr (LL == 6) sync();
+            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) sync();   // one buffer: the stores stay behind the reads that filled x
             store_group<G>(buf, t, x);
             sync();
             load_group<G + 1>(buf, t, x);
@@ -183,7 +189,7 @@ struct PolyNtt {
         inv_group<G>(x, t, tw);
         if constexpr (G > 0) {
             double *buf = xc.next();
-            if constexpr (LL == 6) sync();
+            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) sync();   // one buffer: the stores stay behind the reads that filled x
             store_group<G>(buf, t, x);
             sync();
             load_group<G - 1>(buf, t, x);
@@ -227,9 +233,9 @@ struct PolyNtt {
 // wherever the polynomial has them.
 //   N <= 1024: one wave per polynomial: exchanges are wave-private, no barrier inside a transform
 //              (N = 1024: 14.3 ms against 17.7 ms for two waves with E = 8, at the time both were measured);
-//   N  = 2048: two waves per polynomial, E = 16, one workgroup barrier per exchange, two exchanges per transform
-//              (34.4 ms against 39.7 ms for four waves with E = 8 and three exchanges; before the kernel's register
-//              diet the E = 16 form spilled and lost, 62 against 42 ms).
+//   N  = 2048: two waves per polynomial, E = 16, two exchanges per transform through one buffer (two workgroup barriers
+//              each) with the twiddle tables in the LDS a ping-pong pair would have taken: 23.7 ms; with the ping-pong
+//              pair and twiddles from global memory 27.5; four waves with E = 8 and three exchanges 39.7 (l = 4).
 #ifdef FBS_COEFS_PER_LANE_LOG2   // experiments: force 2^k coefficients per lane everywhere it is possible
 __host__ __device__ constexpr int lanes_log2_for(int log_n) {
     return log_n - FBS_COEFS_PER_LANE_LOG2 < 6 ? 6 : log_n - FBS_COEFS_PER_LANE_LOG2;
