@@ -133,8 +133,9 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     }
 
     // Rounding runs on doubles too (floor(x * 2^-s + c) is exact on integers): abar = (d + 2^(s-1)) >> s with
-    // s = 46 - l*beta, d the centred residue, abar kept mod B^l.  Adding B/2 at every digit position turns the balanced digits (each in [-B/2, B/2), carries
-    // included) into plain bit fields:  digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
+    // s = 46 - l*beta, d the centred residue, abar kept mod B^l.  Adding B/2 at every digit position turns the
+    // balanced digits (each in [-B/2, B/2), carries included) into plain bit fields:
+    //     digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
     // Flipping the top bit of every field then leaves digit_j in two's complement, ready for a signed bit-field extract.
     const uint32_t bhalf = 1u << (a.beta - 1);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             continue;
         }
 
-        // ---- (X^r - 1) * ACC_c, canonical, rounded to the closest multiple of q / B^l -------------
+        // ---- (X^r - 1) * ACC_c, centred, rounded to the closest multiple of q / B^l ---------------
         uint32_t digits[E];
         {
             double *buf = xc.next();
@@ -226,7 +227,8 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         {
             const uint32_t slot = xc.pp ? xc.stride : 0;
             xc.pp ^= 1u;
-            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) __syncthreads();   // one-buffer exchanges: the partner may still be inside its own
+            // one-buffer exchanges: the partner may still be reading its buffer, which is where this hand-off lands
+            if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) __syncthreads();
 #pragma unroll
             for (int m = 0; m < E; m++) theirs[slot + m * LANES + t] = other[m];
             __syncthreads();
