@@ -511,18 +511,18 @@ static void poly_rotate(const uint64_t *in, uint64_t *out, uint32_t r, uint32_t 
     }
 }
 
-/* signed balanced digits of the closest multiple of q/B^l; out[lv][j] as field elements.
- * The rounding treats q as 2^46 (a shift), which scales the value by 2^46/q = 1 + 7.2e-9.  Applied to the canonical
- * residue in [0, q) that error is always of one sign and adds up coherently through the N/2 key bits (measured: it
- * dominated the bootstrap noise once l*beta >= 24); applied to the CENTRED residue in (-q/2, q/2] it averages out.
- * So: centre, round half up to a multiple of 2^s (s = 46 - l*beta), keep the result mod B^l. */
-static void decompose_poly(const orc_ctx *c, const uint64_t *poly, uint64_t *digits /* l*N */) {
+/* Signed balanced digits of the closest multiple of q/B^l of v (mod q); out[lv][j] as field elements.
+ * v is a SIGNED representative in (-q, q): the difference of two centred residues, not reduced again.
+ * The rounding treats q as 2^46 (a shift), which scales the value by 2^46/q = 1 + 7.2e-9.  Applied to canonical
+ * residues in [0, q) that error is always of one sign and adds up coherently through the N/2 key bits (measured: it
+ * dominated the bootstrap noise once l*beta >= 24); on representatives symmetric around 0 it averages out.
+ * So: round half up to a multiple of 2^s (s = 46 - l*beta), keep the result mod B^l. */
+static void decompose_poly(const orc_ctx *c, const int64_t *poly, uint64_t *digits /* l*N */) {
     uint32_t N = c->N, l = c->p.l_bsk, beta = c->p.beta_bsk;
     uint64_t B = 1ull << beta, half = B >> 1;
     const int s = ORC_QBITS - (int)(l * beta);
     for (uint32_t j = 0; j < N; j++) {
-        int64_t v = poly[j] > ORC_Q / 2 ? (int64_t)poly[j] - (int64_t)ORC_Q : (int64_t)poly[j];
-        int64_t t = v + ((int64_t)1 << (s - 1));
+        int64_t t = poly[j] + ((int64_t)1 << (s - 1));
         int64_t r = t >= 0 ? t >> s : -((-t + ((int64_t)1 << s) - 1) >> s);   /* floor(t / 2^s) */
         uint64_t abar = (uint64_t)r & ((1ull << (l * beta)) - 1);
         for (int lv = (int)l - 1; lv >= 0; lv--) {
@@ -537,10 +537,14 @@ static void decompose_poly(const orc_ctx *c, const uint64_t *poly, uint64_t *dig
     }
 }
 
+/* centred representative in [-(q-1)/2, (q-1)/2] */
+static inline int64_t centred(uint64_t a) { return a > ORC_Q / 2 ? (int64_t)a - (int64_t)ORC_Q : (int64_t)a; }
+
 void orc_blind_rotate(const orc_ctx *c, const uint32_t *ms, const uint64_t *tv, uint64_t *acc) {
     uint32_t N = c->N, k = c->p.k, n = c->p.n, l = c->p.l_bsk;
     uint32_t comps = k + 1, twoN = 2 * N;
-    uint64_t *diff = malloc((size_t)comps * N * 8);
+    uint64_t *rot = malloc((size_t)N * 8);
+    int64_t *diff = malloc((size_t)comps * N * 8);
     uint64_t *dig = malloc((size_t)l * N * 8);
     uint64_t *sum = malloc((size_t)comps * N * 8);
     memset(acc, 0, (size_t)k * N * 8);
@@ -549,9 +553,10 @@ void orc_blind_rotate(const orc_ctx *c, const uint32_t *ms, const uint64_t *tv, 
         uint32_t r = ms[i];
         if (r == 0) continue; /* X^0*ACC - ACC = 0 */
         for (uint32_t cc = 0; cc < comps; cc++) {
-            uint64_t *dcc = diff + (size_t)cc * N;
-            poly_rotate(acc + (size_t)cc * N, dcc, r, N);
-            for (uint32_t j = 0; j < N; j++) dcc[j] = gl_sub(dcc[j], acc[(size_t)cc * N + j]);
+            /* (X^r - 1) * ACC over the centred representatives, as an integer in (-q, q): not reduced again */
+            int64_t *dcc = diff + (size_t)cc * N;
+            poly_rotate(acc + (size_t)cc * N, rot, r, N);
+            for (uint32_t j = 0; j < N; j++) dcc[j] = centred(rot[j]) - centred(acc[(size_t)cc * N + j]);
         }
         memset(sum, 0, (size_t)comps * N * 8);
         for (uint32_t cc = 0; cc < comps; cc++) {
@@ -571,6 +576,7 @@ void orc_blind_rotate(const orc_ctx *c, const uint32_t *ms, const uint64_t *tv, 
             for (uint32_t j = 0; j < N; j++) acc[(size_t)oc * N + j] = gl_add(acc[(size_t)oc * N + j], s[j]);
         }
     }
+    free(rot);
     free(diff);
     free(dig);
     free(sum);

@@ -82,9 +82,9 @@ def test_bootstrap_bit_exact_all_sizes(nat, toy_params, log_n):
 
 
 @pytest.mark.parametrize("l,beta,t,gamma", [(1, 8, 8, 2), (2, 8, 4, 4), (2, 12, 3, 5), (3, 7, 16, 1), (4, 6, 2, 6), (5, 4, 8, 3),
-                                            (6, 5, 1, 6), (1, 20, 31, 1), (10, 3, 5, 5), (2, 15, 8, 2), (1, 31, 8, 2)])
+                                            (6, 5, 1, 6), (1, 20, 31, 1), (10, 3, 5, 5), (2, 15, 8, 2), (1, 30, 8, 2)])
 def test_bootstrap_bit_exact_all_decompositions(nat, toy_params, l, beta, t, gamma):
-    """Gadget shapes other than the default: digit widths from 3 to 20 bits (balanced digits with carries through
+    """Gadget shapes other than the default: digit widths from 3 to 30 bits (balanced digits with carries through
     every level), 1 to 10 levels, key-switch bases from 2 to 2^6 -- ciphertexts identical to the oracle's.  Not every
     shape leaves room for the message (a 1-level 8-bit gadget is pure rounding noise); parity does not care."""
     prm = toy_params.replace(l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=gamma)

@@ -120,7 +120,8 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     const uint64_t *tv = a.tvs + (size_t)table * N;
     const uint32_t rows = 2 * a.l;
 
-    // ACC = (0, X^{-b~} * TV), canonical; register m of lane t is coefficient t + LANES*m
+    // ACC = (0, X^{-b~} * TV), kept CENTRED (|.| <= (q-1)/2) for the whole rotation; register m of lane t is
+    // coefficient t + LANES*m
     double acc[E];
     {
         const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
@@ -128,18 +129,19 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         for (int m = 0; m < E; m++) {
             const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
             const uint64_t v = tv[idx & (N - 1)];
-            acc[m] = comp ? fp_from_u64((idx & N) ? fq_neg(v) : v) : 0.0;
+            acc[m] = comp ? fp_center(fp_from_u64((idx & N) ? fq_neg(v) : v)) : 0.0;
         }
     }
 
     // Rounding runs on doubles too (floor(x * 2^-s + c) is exact on integers): abar = (d + 2^(s-1)) >> s with
-    // s = 46 - l*beta, d the centred residue, abar kept mod B^l.  Adding B/2 at every digit position turns the
+    // s = 46 - l*beta, d = the difference of two centred residues (an integer in (-q, q), not reduced again), abar
+    // kept mod B^l -- B^l is added so that the value converted to an unsigned word is positive (l*beta <= 30).  Adding B/2 at every digit position turns the
     // balanced digits (each in [-B/2, B/2), carries included) into plain bit fields:
     //     digit_j = ((abar + (B/2)(1 + B + .. + B^(l-1))) >> j*beta) mod B - B/2.
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
     // Flipping the top bit of every field then leaves digit_j in two's complement, ready for a signed bit-field extract.
     const uint32_t bhalf = 1u << (a.beta - 1);
-    double round_offset = 0.5;
+    double round_offset = 0.5 + fp_exp2i((int)(a.l * a.beta));
     uint32_t sign_bits = 0;
     for (uint32_t j = 0; j < a.l; j++) {
         round_offset += (double)(bhalf << (j * a.beta));
@@ -173,10 +175,11 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 const uint32_t idx = from + (uint32_t)LANES * m;   // < 3N: bit LOGN = sign, bits below = position
                 const double w = buf[idx & (N - 1)];
                 const double v = __hiloint2double(__double2hiint(w) ^ (int)((idx << (31 - LOGN)) & 0x80000000u), __double2loint(w));
-                // centred, not canonical: the rounding below treats q as 2^46, an error proportional to the value --
-                // of one sign on [0, q) (it then adds up coherently through the key bits), symmetric on (-q/2, q/2]
-                const double d = fp_center(v - acc[m]);          // (-2q, q) -> [-q/2, q/2]
-                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;   // truncation = floor, < 2^(l*beta+1)
+                // Signed representatives, not canonical ones: the rounding below treats q as 2^46, an error proportional
+                // to the value -- of one sign on [0, q) (it then adds up coherently through the key bits), symmetric
+                // here.  v and acc are centred, so the difference needs no reduction of its own.
+                const double d = v - acc[m];                     // in (-q, q)
+                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;   // truncation = floor, < 3 * 2^(l*beta)
             }
         }
 
@@ -239,7 +242,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
         W::template inverse<SMALL_DIGITS>(own, xc, t, twi, inv_uni);
 #pragma unroll
-        for (int m = 0; m < E; m++) acc[m] = fp_canon_near(acc[m] + own[m]);   // |.| <= 9 q
+        for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);   // |.| <= 9 q -> centred
     }
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
@@ -249,12 +252,12 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const uint32_t j = t + (uint32_t)LANES * m;
-            const uint64_t v = fp_to_u64(acc[m]);
+            const uint64_t v = fp_to_u64(fp_canon(acc[m]));
             if (j == 0) out[0] = v;
             else out[N - j] = fq_neg(v);
         }
     } else if (t == 0) {
-        out[N] = fq_add(fp_to_u64(acc[0]), a.post[table]);
+        out[N] = fq_add(fp_to_u64(fp_canon(acc[0])), a.post[table]);
     }
 }
 

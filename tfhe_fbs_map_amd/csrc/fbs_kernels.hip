@@ -251,8 +251,8 @@ int dev_supported(const fbs_ctx *ctx) {
     if (p.k != 1) return set_error(ctx, FBS_E_INVALID, "this build supports GLWE dimension k = 1 only");
     if (p.log_n_poly < 8 || p.log_n_poly > 11)
         return set_error(ctx, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048");
-    if (p.l_bsk < 1 || p.beta_bsk < 1 || p.l_bsk * p.beta_bsk > 31 || p.l_bsk * p.beta_bsk > FQ_BITS - 2)
-        return set_error(ctx, FBS_E_INVALID, "need 1 <= l*beta <= 31");
+    if (p.l_bsk < 1 || p.beta_bsk < 1 || p.l_bsk * p.beta_bsk > 30 || p.l_bsk * p.beta_bsk > FQ_BITS - 2)
+        return set_error(ctx, FBS_E_INVALID, "need 1 <= l*beta <= 30");
     if (p.t_ksk < 1 || p.gamma_ksk < 1 || p.t_ksk * p.gamma_ksk > 31 || p.t_ksk * p.gamma_ksk > FQ_BITS - 2)
         return set_error(ctx, FBS_E_INVALID, "need 1 <= t*gamma <= 31");
     if (p.n < 1 || p.n > 4096) return set_error(ctx, FBS_E_INVALID, "need 1 <= n <= 4096");
