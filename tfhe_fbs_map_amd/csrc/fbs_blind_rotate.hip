@@ -282,6 +282,16 @@ static int upload_keys_t(fbs_ctx *ctx) {
                            reinterpret_cast<double *>(ctx->d_bsk_hat), reinterpret_cast<const double *>(ctx->d_tw_fwd), n_inv,
                            polys);
         e = hipGetLastError();
+        constexpr int LLS = lanes_log2_for_small_launch(LOGN);
+        if constexpr (LLS != LL) {
+            if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((k_bsk_transform<LOGN, LLS>), dim3(grid), dim3(1 << LLS), 0, ctx->stream, d_src,
+                                   reinterpret_cast<double *>(ctx->d_bsk_hat_small), reinterpret_cast<const double *>(ctx->d_tw_fwd),
+                                   n_inv, polys);
+                e = hipGetLastError();
+            }
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_src);
@@ -346,14 +356,24 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
     const bool small_digits = p.beta_bsk <= 9 && p.l_bsk <= 5;
+    // at most one bootstrap per CU: the shape with twice the waves per bootstrap, where there is one (fbs_ntt.hpp)
+    const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
     switch (p.log_n_poly) {
-#define LAUNCH(L, SMALL, FPW)                                                                                          \
-    hipLaunchKernelGGL((k_blind_rotate<L, lanes_log2_for(L), SMALL, FPW>), grid, dim3((2 << lanes_log2_for(L)) * FPW), 0,     \
-                       stream, a)
+#define LAUNCH_LL(L, LL_, SMALL, FPW)                                                                                  \
+    hipLaunchKernelGGL((k_blind_rotate<L, LL_, SMALL, FPW>), grid, dim3((2 << (LL_)) * FPW), 0, stream, a)
+#define LAUNCH(L, SMALL, FPW) LAUNCH_LL(L, lanes_log2_for(L), SMALL, FPW)
 #define X(L)                                                                                                           \
     case L:                                                                                                            \
+        if constexpr (lanes_log2_for_small_launch(L) != lanes_log2_for(L)) {                                           \
+            if (small_launch) {                                                                                        \
+                a.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);                                    \
+                if (small_digits) LAUNCH_LL(L, lanes_log2_for_small_launch(L), true, 1);                               \
+                else LAUNCH_LL(L, lanes_log2_for_small_launch(L), false, 1);                                           \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
         if constexpr (lanes_log2_for(L) == 6) {                                                                        \
             if (pair && small_digits) LAUNCH(L, true, 2);                                                              \
             else if (pair) LAUNCH(L, false, 2);                                                                        \
@@ -367,6 +387,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         FBS_FOR_EACH_SHAPE(X)
 #undef X
 #undef LAUNCH
+#undef LAUNCH_LL
         default: return set_error(ctx, FBS_E_INVALID, "unsupported N");
     }
     prof_end(ctx, 1, stream, e0, e1);

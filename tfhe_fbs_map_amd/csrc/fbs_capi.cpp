@@ -132,7 +132,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_ksk, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
                     (void *)ctx->d_idx})
         if (p) (void)hipFree(p);
     for (auto &v : ctx->prof.pending)

@@ -64,6 +64,7 @@ struct fbs_ctx {
     std::vector<uint64_t> sk_lwe, sk_glwe, bsk, ksk;   // host copies, standard layout
 
     uint64_t *d_bsk_hat = nullptr;   // [n][rows][k+1][N]  NTT domain, lane-interleaved, x N^-1
+    uint64_t *d_bsk_hat_small = nullptr;   // the same in the evaluation order of the small-launch shape (fbs_ntt.hpp), or null
     uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
     uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
     uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)

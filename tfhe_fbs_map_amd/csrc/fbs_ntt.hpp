@@ -236,6 +236,12 @@ struct PolyNtt {
 //   N  = 2048: two waves per polynomial, E = 16, two exchanges per transform through one buffer (two workgroup barriers
 //              each) with the twiddle tables in the LDS a ping-pong pair would have taken: 23.7 ms; with the ping-pong
 //              pair and twiddles from global memory 27.5; four waves with E = 8 and three exchanges 39.7 (l = 4).
+// A second shape for launches that leave most of the chip empty (at most one bootstrap per CU): N = 1024 as two waves
+// per polynomial with 8 coefficients per lane -- twice the waves per bootstrap, 4.95 ms against 5.56 ms per launch.
+// It needs its own transformed copy of the bootstrapping key (the evaluation order differs).  Same as the main
+// shape where there is no such alternative.
+__host__ __device__ constexpr int lanes_log2_for_small_launch(int log_n) { return log_n == 10 ? 7 : (log_n <= 10 ? 6 : log_n - 4); }
+
 #ifdef FBS_COEFS_PER_LANE_LOG2   // experiments: force 2^k coefficients per lane everywhere it is possible
 __host__ __device__ constexpr int lanes_log2_for(int log_n) {
     return log_n - FBS_COEFS_PER_LANE_LOG2 < 6 ? 6 : log_n - FBS_COEFS_PER_LANE_LOG2;
