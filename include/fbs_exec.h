@@ -16,10 +16,17 @@
  * bound to one GPU and must be driven by one host thread at a time.  There is
  * no CPU fallback: without a usable gfx950 device `fbs_ctx_create` fails.
  *
- * Ciphertexts are LWE samples over Z_q, q = 2^64 - 2^32 + 1, under the "big"
- * key of dimension D = k*N: D mask words then the body, all canonical (< q).
- * A message m in [0, 2p) is encoded as m * Delta, Delta = 2*round(q/4p), with
- * p = `p_msg` the reference's `fbs_size` (map_circuit.py:97,117-122).
+ * Ciphertexts are LWE samples over Z_q, q = 2^46 - 62*2^13 + 1 = 0x3FFFFFF84001
+ * (prime; the ciphertext modulus and the NTT modulus are the same), one residue
+ * per 64-bit word, under the "big" key of dimension D = k*N: D mask words then
+ * the body, all canonical (< q).  A message m in [0, 2p) is encoded as
+ * m * Delta, Delta = 2*round(q/4p), with p = `p_msg` the reference's `fbs_size`
+ * (map_circuit.py:97,117-122).
+ *
+ * Streams.  Entry points that take a `stream` queue their work on it and return
+ * without waiting.  All calls on a context share its scratch buffers: calls on
+ * one stream are ordered by the stream, and a call on a different stream first
+ * waits (on the device) for the previous call that used the scratch.
  */
 #ifndef FBS_EXEC_H
 #define FBS_EXEC_H
@@ -45,8 +52,8 @@ typedef struct fbs_params {
     uint32_t t_ksk;      /* key-switch levels (8)                                 */
     uint32_t gamma_ksk;  /* log2 key-switch base (2)                              */
     uint32_t p_msg;      /* plaintext modulus p = fbs_size                        */
-    uint64_t sigma_lwe;  /* std-dev of key-switch-key noise, absolute (x q/2^64)  */
-    uint64_t sigma_glwe; /* std-dev of bootstrap-key and fresh-input noise        */
+    uint64_t sigma_lwe;  /* std-dev of key-switch-key noise, in units of 1/q       */
+    uint64_t sigma_glwe; /* std-dev of bootstrap-key and fresh-input noise, same  */
 } fbs_params;
 
 typedef struct fbs_ctx fbs_ctx;
@@ -106,7 +113,9 @@ int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d
 /* ---- linear combination (LinearProd, fbs_exec_env.py:37-49, :215-217) ------
  * out[g][s] = sum_i coefs[off[g]+i] * wires[srcs[off[g]+i]][s] + consts[g]*Delta  for g < n_out,
  * s < T.  `d_wires` is a device array laid out [wire][T][D+1]; outputs are written to wire
- * slots dst[g] of the same array.  term_off has n_out+1 entries.  Host index arrays. */
+ * slots dst[g] of the same array.  term_off has n_out+1 entries.  HOST index arrays: this call
+ * and fbs_bootstrap_wires_dev stage them through a per-context buffer and wait for that copy
+ * (a convenience for tests and one-off calls; to step a program use fbs_level_* below). */
 int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *dst,
                     const uint32_t *term_off, const uint32_t *srcs, const int64_t *coefs, const int64_t *consts,
                     void *stream);
@@ -138,8 +147,49 @@ void fbs_program_destroy(fbs_prog *prog);
 /* depth (number of bootstrap levels) and the widest level, as scheduled */
 int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap);
 /* in_cts: host [n_inputs][T][D+1]; out_cts: host [n_outputs][T][D+1] (constant outputs are
- * written as trivial ciphertexts).  Levels are batched over (gate, sample). */
+ * written as trivial ciphertexts).  Levels are batched over (gate, sample); samples are
+ * evaluated in chunks whose wire slots fit in HBM. */
 int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts);
+/* the same on device-resident buffers, asynchronous on `stream` */
+int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, uint64_t *d_out, void *stream);
+
+/* ---- a loaded program, one level at a time (multi-GPU hosts) -----------------
+ * The two independent axes of the reference's eval loop (fbs_exec_env.py:211-223) are the gates
+ * of a bootstrap level and the samples.  A host that shards the GATES of a level over several
+ * GPUs keeps a replicated wire buffer per GPU, [n_slots][T][D+1] words of its own device
+ * memory, and steps the program with the calls below; every index array they need was
+ * uploaded by fbs_program_load, so each call is a few kernel launches on `stream` and
+ * nothing else.  Wires live in SLOTS: a wire's slot is reused once its last reader has run,
+ * so n_slots is the peak number of live wires, not the number of wires.
+ *   level L in [0, n_levels]:  fbs_level_lincomb_dev    the LinearProds of level L
+ *   level L in [0, n_levels):  fbs_level_bootstrap_dev  bootstraps f in [f_begin, f_end) of the
+ *        level's [n_gates][s_count] grid (gate-major), each preceded by the key switch of its
+ *        source -- one key switch per distinct (source wire, sample), shared by the gates that
+ *        read it.  d_rows == NULL: results go to their wire slots; else to row f - f_begin of
+ *        d_rows ([f_end - f_begin][D+1], e.g. the send buffer of an all-gather), and
+ *   fbs_level_scatter_dev copies rows of such an array (after the all-gather) into the slots.
+ * Samples [s_begin, s_begin + s_count) of every wire are processed; T is the sample stride. */
+typedef struct fbs_layout {
+    uint32_t n_slots;      /* wire slots a wire buffer needs                                   */
+    uint32_t n_levels;     /* bootstrap levels                                                 */
+    uint32_t max_width;    /* bootstraps in the widest level                                   */
+    uint32_t max_sources;  /* key switches in the level that has most                          */
+    uint32_t n_bootstrap;  /* bootstraps in the program                                        */
+    uint32_t n_keyswitch;  /* key switches in the program (<= n_bootstrap: shared sources)     */
+    uint32_t n_inputs, n_outputs;
+} fbs_layout;
+int fbs_program_layout(const fbs_prog *prog, fbs_layout *out);
+int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources);
+/* in_slot[n_inputs]: where input i is expected; out_slot[n_outputs]: slot of output o, or -1-c for a constant c */
+int fbs_program_io_slots(const fbs_prog *prog, uint32_t *in_slot, int64_t *out_slot);
+int fbs_level_lincomb_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T,
+                          size_t s_begin, size_t s_count, void *stream);
+int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T,
+                            size_t s_begin, size_t s_count, size_t f_begin, size_t f_end, uint64_t *d_rows,
+                            void *stream);
+int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T,
+                          size_t s_begin, size_t s_count, const uint64_t *d_rows, size_t f_begin, size_t f_end,
+                          void *stream);
 
 /* ---- measurement hooks ------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its own

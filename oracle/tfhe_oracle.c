@@ -486,14 +486,22 @@ void orc_keyswitch(const orc_ctx *c, const uint64_t *ct_big, uint64_t *ct_small)
     uint32_t tg = t * gam;
     for (uint32_t i = 0; i < n; i++) ct_small[i] = 0;
     ct_small[n] = ct_big[d];
+    const int64_t base = 1ll << gam;
     for (uint32_t j = 0; j < d; j++) {
-        /* closest multiple of q/2^(t*gamma): top t*gamma bits, rounded; unsigned digits */
-        uint64_t abar = ((ct_big[j] >> (ORC_QBITS - 1 - tg)) + 1) >> 1;
-        for (uint32_t v = 0; v < t; v++) {
-            uint64_t dig = (abar >> (gam * (t - 1 - v))) & ((1ull << gam) - 1);
+        /* closest multiple of q/2^(t*gamma): top t*gamma bits, rounded, kept mod 2^(t*gamma) (the dropped carry is a
+         * multiple of q); then BALANCED digits in [-B/2, B/2), least significant first, carries propagated */
+        uint64_t abar = (((ct_big[j] >> (ORC_QBITS - 1 - tg)) + 1) >> 1) & ((1ull << tg) - 1);
+        for (uint32_t v = t; v-- > 0;) {
+            int64_t dig = (int64_t)(abar & (uint64_t)(base - 1));
+            abar >>= gam;
+            if (dig >= base / 2 && base > 1) {
+                dig -= base;
+                abar += 1;
+            }
             if (!dig) continue;
             const uint64_t *row = c->ksk + ((size_t)j * t + v) * (n + 1);
-            for (uint32_t i = 0; i <= n; i++) ct_small[i] = gl_sub(ct_small[i], gl_mul(dig, row[i]));
+            uint64_t df = gl_from_i64(dig);
+            for (uint32_t i = 0; i <= n; i++) ct_small[i] = gl_sub(ct_small[i], gl_mul(df, row[i]));
         }
     }
 }

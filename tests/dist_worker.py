@@ -13,38 +13,70 @@ sys.path.insert(0, ROOT)
 
 from oracle import lut_oracle, tfhe_oracle as orc      # noqa: E402
 from tests.helpers import load_fixture, oracle_eval_program, subsample      # noqa: E402
+from tfhe_fbs_map_amd.distributed import plan_levels      # noqa: E402
 
 
 class OracleBackend:
-    def __init__(self, o, tables):
-        self.o, self.tables, self.ctw = o, tables, o.ctw
+    """The backend interface of tfhe_fbs_map_amd.distributed on host memory: wires are [n_wires * T, ctw] (slot = wire
+    id, no reuse), the arithmetic is the CPU oracle's."""
+
+    def __init__(self, o, low):
+        self.o, self.tables, self.ctw = o, low["tables"], o.ctw
+        self.plan = plan_levels(low)
+        self.low = low
+        self.depth = self.plan["depth"]
+        self.level_width = [len(b["src"]) for b in self.plan["boot"]]
+        self.n_inputs, self.n_outputs = self.plan["n_inputs"], len(low["out_wire"])
         self.calls = []
 
-    def new_wires(self, n_wires, T):
-        return torch.zeros((n_wires * T, self.ctw), dtype=torch.int64)
+    def new_wires(self, T):
+        return torch.zeros((self.plan["n_wires"] * max(1, T), self.ctw), dtype=torch.int64)
 
-    def upload(self, wires, row0, cts):
-        flat = torch.from_numpy(np.ascontiguousarray(cts, np.uint64).reshape(-1, self.ctw).view(np.int64))
-        wires[row0:row0 + flat.shape[0]].copy_(flat)
+    def new_rows(self, rows):
+        return torch.zeros((max(1, rows), self.ctw), dtype=torch.int64)
 
-    def download(self, wires, rows):
-        return wires[rows].numpy().view(np.uint64)
-
-    def lincomb(self, wires, T, st):
+    def load_inputs(self, wires, T, in_cts, s_count):
+        src = np.ascontiguousarray(in_cts, np.uint64).reshape(self.n_inputs, s_count, self.ctw)
         w = wires.numpy().view(np.uint64)
-        for g, dst in enumerate(st["dst"]):
-            terms = range(st["term_off"][g], st["term_off"][g + 1])
-            for s in range(T):
-                w[dst * T + s] = self.o.lincomb([w[st["srcs"][t] * T + s] for t in terms],
-                                                [st["coefs"][t] for t in terms], st["consts"][g])
+        for i in range(self.n_inputs):
+            w[i * T:i * T + s_count] = src[i]
 
-    def bootstrap(self, wires, T, src, dst, table, s_begin, s_end):
+    def lincomb_level(self, wires, T, L, s_count):
         w = wires.numpy().view(np.uint64)
-        self.calls.append((len(src), s_begin, s_end))
-        for g in range(len(src)):
-            rows = slice(src[g] * T + s_begin, src[g] * T + s_end)
-            out, _ = self.o.bootstrap_batch(w[rows], [self.tables[table[g]]], None, threads=1)
-            w[dst[g] * T + s_begin:dst[g] * T + s_end] = out
+        for st in self.plan["lin"][L]:
+            for g, dst in enumerate(st["dst"]):
+                terms = range(st["term_off"][g], st["term_off"][g + 1])
+                for s in range(s_count):
+                    w[dst * T + s] = self.o.lincomb([w[st["srcs"][t] * T + s] for t in terms],
+                                                    [st["coefs"][t] for t in terms], st["consts"][g])
+
+    def bootstrap_level(self, wires, T, L, s_count, f0, f1, rows=None):
+        w = wires.numpy().view(np.uint64)
+        b = self.plan["boot"][L]
+        self.calls.append(f1 - f0)
+        r = None if rows is None else rows.numpy().view(np.uint64)
+        for f in range(f0, f1):
+            g, s = divmod(f, s_count)
+            out, _ = self.o.bootstrap_batch(w[b["src"][g] * T + s][None], [self.tables[b["table"][g]]], None, threads=1)
+            if r is None:
+                w[b["dst"][g] * T + s] = out[0]
+            else:
+                r[f - f0] = out[0]
+
+    def scatter_level(self, wires, T, L, s_count, rows, f0, f1):
+        w = wires.numpy().view(np.uint64)
+        r = rows.numpy().view(np.uint64)
+        b = self.plan["boot"][L]
+        for f in range(f0, f1):
+            g, s = divmod(f, s_count)
+            w[b["dst"][g] * T + s] = r[f - f0]
+
+    def read_outputs(self, wires, T, s_count):
+        out = torch.zeros((self.n_outputs, s_count, self.ctw), dtype=torch.int64)
+        for k, wire in enumerate(self.low["out_wire"]):
+            if wire >= 0:
+                out[k] = wires[wire * T:wire * T + s_count]
+        return out
 
 
 def main():
@@ -63,12 +95,12 @@ def main():
     cts = np.stack([o.encrypt(ins[n], nonce0=100 * i) for i, n in enumerate(low["input_names"])])
     res = {}
     for mode, cls in (("gate", GateShardedRunner), ("sample", SampleShardedRunner)):
-        be = OracleBackend(o, low["tables"])
-        runner = cls(low, be)
+        be = OracleBackend(o, low)
+        runner = cls(be)
         out = runner.run(cts, T)
         res[mode] = out
         res[mode + "_collectives"] = runner.collectives
-        res[mode + "_fbs_done"] = sum(g * (b - a) for g, a, b in be.calls)
+        res[mode + "_fbs_done"] = sum(be.calls)
     if rank == 0:
         # single-process answer by the plain instruction-by-instruction evaluation
         ops, outs = lut_oracle.read_fbs(rec["fbs"])

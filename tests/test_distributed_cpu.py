@@ -10,23 +10,18 @@ import pytest
 
 from tests.helpers import load_fixture, subsample
 from tfhe_fbs_map_amd import parse_fbs
-from tfhe_fbs_map_amd.distributed import plan_levels, rectangles, split_range
+from tfhe_fbs_map_amd.distributed import plan_levels, split_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_split_and_rectangles_cover_exactly():
+def test_split_covers_exactly():
     for total, parts in ((10, 3), (7, 8), (64, 2), (1, 2), (0, 2)):
         got = []
         for r in range(parts):
             a, b, _ = split_range(total, parts, r)
             got += list(range(a, b))
         assert got == list(range(total))
-    for f0, f1, T in ((0, 10, 4), (3, 4, 4), (3, 13, 4), (5, 5, 4), (0, 8, 4), (2, 3, 1)):
-        cells = []
-        for g0, g1, s0, s1 in rectangles(f0, f1, T):
-            cells += [g * T + s for g in range(g0, g1) for s in range(s0, s1)]
-        assert cells == list(range(f0, f1))
 
 
 def test_plan_matches_facade_schedule():

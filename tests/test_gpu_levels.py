@@ -1,0 +1,157 @@
+"""The loaded program, one level at a time (include/fbs_exec.h "a loaded program, one level at a time"): what the
+multi-GPU runners are built from.  Shared key switches, wire-slot reuse, slices of a level into contiguous rows and
+back, the device-buffer whole-program call, and the two runners on the nccl backend (RCCL) with one rank -- all
+against `fbs_eval` and the CPU oracle, word for word."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import lut_oracle, tfhe_oracle as orc
+from tests.helpers import load_fixture, oracle_eval_program, subsample
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from tfhe_fbs_map_amd import _native
+    return _native
+
+
+def load(nat, toy_params, name, T, seed=6, merge=True):
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture(name)
+    ops, outs = lut_oracle.read_fbs(rec["fbs"])
+    tables = [op[3] for op in ops if op[0] == "boot"]
+    p = max(7, max(len(t) for t in tables))
+    prm = toy_params.replace(p_msg=p)
+    ctx = nat.Context(prm, seed=seed)
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"], merge_linear_prods=merge)
+    low = env.lower()
+    ins, expect = subsample(rec, T)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
+    prog = nat.Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                       low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    return rec, ctx, prm, low, cts, prog, expect, (ops, outs)
+
+
+@pytest.mark.parametrize("name", ["adder8__basic_p2", "2_input_gates__basic_p2", "aes_sbox__basic_p2"])
+def test_gates_that_share_a_source_share_its_key_switch(nat, toy_params, name):
+    """The reference's one-gate-one-bootstrap lowering puts several tables on one linear combination
+    (map_to_fbs.py:41-45; its CSE only merges identical tables, fbs_exec_env.py:93-100): the loaded program runs ONE
+    key switch + modulus switch per distinct source of a level.  Exact: the ciphertexts are those of the oracle, which
+    key-switches per bootstrap."""
+    T = 3
+    rec, ctx, prm, low, cts, prog, expect, (ops, outs) = load(nat, toy_params, name, T)
+    assert prog.n_keyswitch < prog.n_bootstrap, (prog.n_keyswitch, prog.n_bootstrap)
+    assert sum(prog.level_sources) == prog.n_keyswitch and sum(prog.level_width) == prog.n_bootstrap
+    distinct = len({(op[2]) for op in ops if op[0] == "boot"})
+    assert prog.n_keyswitch == distinct                     # every source sits in one level only
+    got = prog.eval(cts, T)
+    o = orc.Oracle(prm, seed=6)
+    wires = oracle_eval_program(o, ops, outs, {n: cts[i] for i, n in enumerate(low["input_names"])})
+    for k, (out_name, src) in enumerate(outs):
+        if src not in ("0", "1"):
+            assert np.array_equal(got[k], wires[src]), out_name
+            assert np.array_equal(ctx.decrypt(got[k]), expect[out_name])
+
+
+def test_search_mapped_programs_have_nothing_to_share(nat, toy_params):
+    _, _, _, _, _, prog, _, _ = load(nat, toy_params, "aes_sbox__search_p7", 1)
+    assert prog.n_keyswitch == prog.n_bootstrap
+
+
+@pytest.mark.parametrize("name", ["adder8__search_p7", "mul4__naive_p7", "adder8__basic_p2"])
+def test_wire_slots_are_reused(nat, toy_params, name):
+    _, _, _, low, _, prog, _, _ = load(nat, toy_params, name, 1)
+    n_wires = len(low["input_names"]) + len(low["kind"])
+    assert prog.n_slots < n_wires
+    assert len(set(prog.in_slot.tolist())) == len(low["input_names"])          # inputs never share a slot
+    live_outputs = [s for s in prog.out_slot.tolist() if s >= 0]
+    assert len(set(live_outputs)) == len(set(w for w in low["out_wire"] if w >= 0))
+
+
+@pytest.mark.parametrize("name,T", [("adder8__basic_p2", 5), ("adder8__search_p7", 4), ("edge_outputs", 3), ("aes_sbox__basic_p2", 2)])
+def test_levels_in_slices_through_rows_and_back(nat, toy_params, name, T):
+    """Every level cut into three ragged slices (cuts inside a gate's samples and between gates that share a source),
+    each slice bootstrapped into a contiguous row buffer and scattered back -- the gate-sharded data path on one GPU
+    -- equals fbs_eval word for word.  The wire buffer has a larger sample stride than the samples in use."""
+    import torch
+    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, name, T)
+    ref = prog.eval(cts, T)
+    ctw = prm.ct_words
+    stride = T + 2
+    wires = torch.zeros((prog.n_slots, stride, ctw), dtype=torch.int64, device="cuda")
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    wires[torch.from_numpy(prog.in_slot.astype(np.int64)).cuda(), :T] = d_in
+    for L in range(prog.depth + 1):
+        prog.level_lincomb_dev(L, wires.data_ptr(), stride, 0, T)
+        if L == prog.depth:
+            break
+        total = prog.level_width[L] * T
+        cuts = sorted({0, total, min(total, max(0, total // 3 + 1)), min(total, (2 * total) // 3 + (1 if T > 1 else 0))})
+        for f0, f1 in zip(cuts, cuts[1:]):
+            rows = torch.full((f1 - f0, ctw), -1, dtype=torch.int64, device="cuda")
+            prog.level_bootstrap_dev(L, wires.data_ptr(), stride, 0, T, f0, f1, d_rows=rows.data_ptr())
+            prog.level_scatter_dev(L, wires.data_ptr(), stride, 0, T, rows.data_ptr(), f0, f1)
+    ctx.sync()
+    got = wires.cpu().numpy().view(np.uint64)
+    for k, slot in enumerate(prog.out_slot.tolist()):
+        if slot >= 0:
+            assert np.array_equal(got[slot, :T], ref[k]), low["out_names"][k]
+
+
+def test_eval_on_device_buffers_equals_eval_on_host_buffers(nat, toy_params):
+    import torch
+    T = 6
+    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, "edge_outputs", T)
+    ref = prog.eval(cts, T)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_out = torch.empty((prog.n_outputs, T, prm.ct_words), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()                       # a second stream: the scratch hand-over is ordered on the device
+    prog.eval_dev(d_in.data_ptr(), T, d_out.data_ptr())
+    with torch.cuda.stream(side):
+        d_out2 = torch.empty_like(d_out)
+        prog.eval_dev(d_in.data_ptr(), T, d_out2.data_ptr(), stream=side.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ref)
+    assert np.array_equal(d_out2.cpu().numpy().view(np.uint64), ref)
+
+
+@pytest.fixture(scope="module")
+def one_rank_nccl():
+    """torch.distributed on the nccl backend (= RCCL) with world size 1: the collective code path of the runners on a
+    real GPU.  More ranks need more GPUs than a test box has; the partition logic is covered on gloo (CPU)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,T", [("adder8__search_p7", 5), ("adder8__basic_p2", 4), ("edge_outputs", 3)])
+def test_runners_on_rccl_equal_program_eval(nat, toy_params, one_rank_nccl, name, T):
+    """GateShardedRunner (send rows -> all_gather_into_tensor -> scatter, forced even with one rank) and
+    SampleShardedRunner on the nccl backend == fbs_eval, word for word."""
+    from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend, SampleShardedRunner
+    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, name, T)
+    ref = prog.eval(cts, T)
+    const = np.array([w < 0 for w in low["out_wire"]])
+    gate = GateShardedRunner(GpuBackend(prog), always_gather=True)
+    got = gate.run(cts, T)
+    assert gate.collectives == prog.depth
+    assert np.array_equal(got[~const], ref[~const])
+    sample = SampleShardedRunner(GpuBackend(prog))
+    assert np.array_equal(sample.run(cts, T)[~const], ref[~const])
+    plain = GateShardedRunner(GpuBackend(prog))                 # one rank, no collective: straight into the slots
+    assert np.array_equal(plain.run(cts, T)[~const], ref[~const]) and plain.collectives == 0
+    for k, name_ in enumerate(low["out_names"]):
+        if not const[k]:
+            assert np.array_equal(ctx.decrypt(got[k]), expect[name_])

@@ -33,7 +33,7 @@ def toy_pair(nat, toy_params):
 
 @pytest.fixture(scope="module")
 def p1024_pair(nat):
-    prm = nat.Params()
+    from tfhe_fbs_map_amd.params import P1024 as prm
     ctx = nat.Context(prm, seed=1)
     return ctx, orc.Oracle(prm, seed=1)
 
@@ -262,29 +262,6 @@ def test_program_ciphertexts_bit_exact(nat, toy_params, name, T):
         else:
             assert np.array_equal(got[k], wires[src]), out_name
             assert np.array_equal(ctx.decrypt(got[k]), expect[out_name])
-
-
-def test_level_runner_on_gpu_equals_program_eval(nat, toy_params):
-    """tfhe_fbs_map_amd.distributed's runners driving the device-pointer C ABI (world size 1 here; the rank
-    partition itself is covered on gloo in tests/test_distributed_cpu.py) == fbs_eval, word for word."""
-    from tfhe_fbs_map_amd import parse_fbs
-    from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend, SampleShardedRunner
-    rec = load_fixture("adder8__search_p7")
-    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
-    low = env.lower()
-    ctx = nat.Context(toy_params.replace(p_msg=7), seed=8)
-    tv = ctx.tvset(low["tables"])
-    T = 5
-    ins, expect = subsample(rec, T)
-    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=3)
-    prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
-                       low["term_coef"], low["term_src"], low["out_wire"])
-    ref = prog.eval(cts, T)
-    for cls in (GateShardedRunner, SampleShardedRunner):
-        got = cls(low, GpuBackend(ctx, tv)).run(cts, T)
-        assert np.array_equal(got, ref), cls.__name__
-    for k, name in enumerate(low["out_names"]):
-        assert np.array_equal(ctx.decrypt(ref[k]), expect[name])
 
 
 def test_output_noise_stays_inside_the_box(p1024_pair):

@@ -72,5 +72,5 @@ def test_random_program(seed):
     buf = io.StringIO()
     env.print(os=buf, show_outputs=True)
     expect = lut_oracle.eval_fbs_text(buf.getvalue(), ins)
-    got = env.eval(ins, config=ExecConfig(fbs_size=P))
+    got = env.eval(ins, config=ExecConfig(fbs_size=P, seed=1, reduced_noise=True))
     assert_outputs_equal(got, {k: (int(v) if np.ndim(v) == 0 else np.asarray(v, np.int64)) for k, v in expect.items()})

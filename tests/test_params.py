@@ -1,18 +1,39 @@
-"""Noise model (tfhe_fbs_map_amd/params.py): the stand-in for the patched concrete-optimizer the reference
-shells out to (experiments/add_exec_estimates.py:9-16)."""
-from tfhe_fbs_map_amd import MODULUS_BITS, P1024, P2048, bootstrap_cost, choose_params, margin_sigmas, params_for
+"""Security floor, noise model and parameter selector (tfhe_fbs_map_amd/params.py): the stand-in for the patched
+concrete-optimizer the reference shells out to (experiments/add_exec_estimates.py:9-16, concrete.patch:21-27,163)."""
+import math
+
+import pytest
+
+from tfhe_fbs_map_amd import MODULUS_BITS, P1024, P2048, Params, bootstrap_cost, choose_params, margin_sigmas, params_for
 from tfhe_fbs_map_amd._native import MODULUS
+from tfhe_fbs_map_amd.params import REFERENCE_MARGIN, p_error, security_bits, sigma_min, variances
+from tfhe_fbs_map_amd.security import log2_sigma_min
 
 
-def test_defaults_have_margin_and_secure_noise_would_not():
+def test_security_floor_table():
     assert MODULUS == (1 << 46) - 62 * (1 << 13) + 1 and MODULUS_BITS == 46
-    # default (reduced) noise: mul16@15 has norm2 84, aes_sbox@15 281 -- comfortably inside the box
+    # the 128-bit line, log2(sigma/q) per dimension (provenance in params.py) ...
+    for dim, want in ((500, -10.3), (630, -13.8), (742, -16.8), (800, -18.3), (1024, -24.3)):
+        assert abs(log2_sigma_min(dim) - want) < 0.06, dim
+    # ... and its floor: nothing below 2^2 in absolute units of a 46-bit modulus
+    assert log2_sigma_min(2048) == -44.0 and sigma_min(2048) == 4
+    assert abs(math.log2(sigma_min(630)) - (46 - 13.78)) < 0.05
+    # published TFHE-rs 128-bit sets sit just below this line (it is the more conservative): n = 742 -> 2^-17.1
+    assert -17.1 < log2_sigma_min(742) < -16.5
+
+
+def test_default_params_are_secure_and_the_benchmark_set_says_it_is_not():
+    d = Params()
+    assert d.sigma_lwe == sigma_min(630) and d.sigma_glwe == sigma_min(1024) and security_bits(d) >= 127.9
+    assert P1024.sigma_lwe == 64 and (P1024.n, P1024.N, P1024.l_bsk, P1024.beta_bsk, P1024.t_ksk, P1024.gamma_ksk) == (630, 1024, 3, 7, 8, 2)
+    assert security_bits(P1024) < 60                                         # reduced noise: a kernel benchmark shape
+    # reduced noise: mul16@15 has norm2 84, aes_sbox@15 281 -- comfortably inside the box
     assert margin_sigmas(P1024.replace(p_msg=15), norm2=84) > 6
     assert margin_sigmas(P1024.replace(p_msg=15), norm2=281) > 5.5
-    # what 128-bit security would need at N=1024 (~2^-25 of q) leaves no room for p=15: documented, not hidden
-    secure = P1024.replace(p_msg=15, sigma_lwe=1 << 21, sigma_glwe=1 << 21)
-    assert margin_sigmas(secure, norm2=84) < 2
-    # p=31 does not fit N=1024 (modulus switch alone) and is sent to N=2048
+    # the same shape at 128-bit noise cannot carry p = 15 (documented, not hidden); it carries p = 2
+    assert margin_sigmas(d.replace(p_msg=15), norm2=1) < 2
+    assert margin_sigmas(d.replace(p_msg=2), norm2=1) > 6
+    # p = 31 does not fit N = 1024 (modulus switch alone) and is sent to N = 2048
     assert margin_sigmas(P1024.replace(p_msg=31), norm2=1) < 4.5
     assert params_for(31).log_n_poly == 11 and params_for(15).log_n_poly == 10
     assert margin_sigmas(params_for(31), norm2=325) > 5
@@ -22,19 +43,52 @@ def test_bytes_per_fbs_is_baselines_figure():
     assert P1024.bytes_per_fbs() == 103_309_328
 
 
-def test_parameter_choice_follows_the_model():
-    """choose_params = the optimizer's role in the reference's flow: cheapest shape with the asked-for margin."""
-    for p, norm2 in ((15, 84), (15, 281), (7, 50), (31, 325), (2, 6)):
-        c = choose_params(p, norm2)
-        assert margin_sigmas(c, norm2) >= 6.0 and c.p_msg == p
-        assert c.log_n_poly == (10 if p <= 16 else 11)
-        assert bootstrap_cost(c) <= bootstrap_cost(params_for(p)) + 1e-9     # never dearer than the fixed default
-    # the reference cost unit: the default N = 1024 set is 1.0 by definition, N = 2048 with one more level costs more
+@pytest.mark.parametrize("p,norm2", [(15, 70), (15, 281), (4, 2), (2, 6), (9, 70)])
+def test_selector_returns_secure_sets_with_the_asked_margin(p, norm2):
+    """The reference's contract (concrete.patch:21-27,163): (precision, sq_norm2) -> n, N, gadget, key switch at a
+    fixed security level and error probability."""
+    c = choose_params(p, norm2)                         # 128 bits, 6 sigma
+    assert c.p_msg == p and c.k == 1
+    assert margin_sigmas(c, norm2) >= 6.0
+    assert c.sigma_lwe >= sigma_min(c.n) and c.sigma_glwe >= sigma_min(c.N) and security_bits(c) >= 127.9
+    # the kernels can run it (dev_supported in csrc/fbs_kernels.hip)
+    assert 8 <= c.log_n_poly <= 11 and c.l_bsk * c.beta_bsk <= 30 and c.t_ksk * c.gamma_ksk <= 31
+    assert MODULUS_BITS + c.gamma_ksk + math.log2(c.t_ksk * c.N) <= 63.9
+    # a looser error probability is never dearer; a larger norm never cheaper
+    assert bootstrap_cost(choose_params(p, norm2, min_margin=REFERENCE_MARGIN)) <= bootstrap_cost(c) + 1e-9
+    assert bootstrap_cost(choose_params(p, norm2 * 4)) >= bootstrap_cost(c) - 1e-9
+
+
+def test_selector_moves_n_and_N():
+    small, big = choose_params(2, 1), choose_params(15, 281)
+    assert small.N == 1024 and big.N == 2048 and big.n > small.n
+    assert choose_params(15, 281).n != choose_params(15, 281, min_margin=4.0).n
+    # p = 31 at norm2 = 325: the modulus switch at N = 2048 leaves 5.9 sigma, so 6 is out of reach ...
+    with pytest.raises(ValueError):
+        choose_params(31, 325)
+    # ... and the executor's default relaxes towards the reference's own 4 sigma
+    c = choose_params(31, 325, floor_margin=REFERENCE_MARGIN)
+    assert c.N == 2048 and margin_sigmas(c, 325) >= 5.0 and security_bits(c) >= 127.9
+
+
+def test_cost_ranking_against_the_references_points():
+    """experiments/analyse_results.py:317,345-353 quotes the patched optimizer's cost per bootstrap: 40 at p = 4
+    (Trivium/Kreyvium), 47 / 69 / 75 at precision 9 / 11 / 17 with sq_norm2 > 2.  Units differ (theirs counts FFT
+    flops of a CPU library, ours FP64 issue slots of these kernels); the ORDER must agree."""
+    ours = [bootstrap_cost(choose_params(p, n2, min_margin=REFERENCE_MARGIN)) for p, n2 in ((4, 3), (9, 3), (11, 3), (17, 3))]
+    theirs = [40, 47, 69, 75]
+    assert all(a <= b for a, b in zip(ours, ours[1:])), ours
+    assert sorted(range(4), key=lambda i: ours[i]) == sorted(range(4), key=lambda i: theirs[i])
+    assert 1.0 < ours[3] / ours[0] < theirs[3] / theirs[0] * 1.5
     assert abs(bootstrap_cost(P1024) - 1.0) < 1e-9 and bootstrap_cost(P2048) > 1.5
-    # more noise -> finer, dearer gadget; hopeless noise -> the best margin available, not an exception
-    noisy = choose_params(3, 20, sigma=1 << 21)
-    assert margin_sigmas(noisy, 20) >= 6.0 and bootstrap_cost(noisy) > bootstrap_cost(choose_params(3, 20))
-    hopeless = choose_params(15, 84, sigma=1 << 21)
-    assert margin_sigmas(hopeless, 84) < 6.0
-    # a larger norm never buys a cheaper set
-    assert bootstrap_cost(choose_params(15, 20000)) >= bootstrap_cost(choose_params(15, 84))
+
+
+def test_reduced_noise_search_and_error_probability():
+    """security=None: the same search at a fixed (benchmark) noise."""
+    c = choose_params(15, 84, security=None)
+    assert c.sigma_lwe == 64 and margin_sigmas(c, 84) >= 6.0 and bootstrap_cost(c) <= bootstrap_cost(P1024)
+    noisy = choose_params(3, 20, security=None, sigma=1 << 21)
+    assert margin_sigmas(noisy, 20) >= 6.0 and bootstrap_cost(noisy) > bootstrap_cost(choose_params(3, 20, security=None))
+    assert 5e-5 < p_error(4.0) < 7e-5 and p_error(6.0) < 3e-9              # "4 sigma" = 6.3e-5 (concrete.patch:56)
+    v_br, v_ks, v_ms = variances(P1024)
+    assert v_ms > v_ks > 0 and v_br > 0

@@ -9,8 +9,8 @@ from . import _native
 from ._native import MODULUS, MODULUS_BITS, Context, FbsError, Params, Program, TvSet
 from .fbs_exec_env import ExecConfig, FbsExecEnv, LutExecEnv, min_fbs_size, parse_fbs, parse_lbf, table_is_valid
 from .netlist import BitExecEnv, map_basic, parse_blif, parse_bristol
-from .params import P1024, P2048, bootstrap_cost, choose_params, margin_sigmas, params_for
+from .params import P1024, P2048, bootstrap_cost, choose_params, margin_sigmas, params_for, security_bits, sigma_min
 
 __all__ = ["Context", "FbsError", "Params", "Program", "TvSet", "ExecConfig", "FbsExecEnv", "LutExecEnv",
            "min_fbs_size", "parse_fbs", "parse_lbf", "table_is_valid", "P1024", "P2048", "margin_sigmas",
-           "params_for", "bootstrap_cost", "choose_params", "BitExecEnv", "map_basic", "parse_blif", "parse_bristol"]
+           "params_for", "bootstrap_cost", "choose_params", "security_bits", "sigma_min", "BitExecEnv", "map_basic", "parse_blif", "parse_bristol"]

@@ -42,7 +42,9 @@ def main(argv=None):
     ap.add_argument("--fbs_size", type=int, default=None, help="plaintext modulus p (default: smallest that fits)")
     ap.add_argument("--inputs", default=None,
                     help="comma-separated input names in harness order (.fbs files do not list their inputs)")
-    ap.add_argument("--seed", type=int, default=1, help="key-generation seed")
+    ap.add_argument("--seed", type=int, default=None, help="key-generation seed (default: fresh from os.urandom)")
+    ap.add_argument("--reduced-noise", action="store_true",
+                    help="benchmark parameter set with reduced noise (NOT secure) instead of the 128-bit selector")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
 
@@ -54,7 +56,7 @@ def main(argv=None):
     np.random.seed(42)
     values = {name: np.random.randint(0, 2, (args.samples)) for name in order}
 
-    cfg = ExecConfig(fbs_size=args.fbs_size, seed=args.seed, device=args.device)
+    cfg = ExecConfig(fbs_size=args.fbs_size, seed=args.seed, device=args.device, reduced_noise=args.reduced_noise)
     stats = env.stats()
     t0 = time.perf_counter()
     out = env.eval(values, config=cfg)          # first call: key generation + upload + program load + run
@@ -66,6 +68,12 @@ def main(argv=None):
                   first_eval_s=round(first, 3), eval_s=round(steady, 3),
                   fbs_per_s=round(stats["nb_bootstrap"] * args.samples / steady, 1) if steady > 0 else None,
                   outputs={str(k): (int(v) if np.ndim(v) == 0 else int(np.asarray(v).sum())) for k, v in out.items()})
+    from dataclasses import asdict
+    from .params import margin_sigmas, security_bits
+    for ctx in cfg._contexts.values():
+        result["params"] = asdict(ctx.params)
+        result["security_bits_estimate"] = round(security_bits(ctx.params), 1)
+        result["margin_sigmas"] = round(margin_sigmas(ctx.params, stats["norm2_linprod"]), 2)
     if bits is not None:
         clear = bits.eval(values)
         result["matches_cleartext_netlist"] = all(

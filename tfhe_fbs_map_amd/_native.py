@@ -15,8 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FBS_LIB") or os.path.join(_HERE, "libfbsexec.so")   # FBS_LIB: kernel-variant experiments
 
-MODULUS = 0x3FFFFFF84001      # q = 2^46 - 62*2^13 + 1 (prime); ciphertext and NTT modulus, 64-bit words
-MODULUS_BITS = 46
+from .security import MODULUS, MODULUS_BITS, sigma_min      # noqa: E402,F401
 
 
 class FbsError(RuntimeError):
@@ -31,6 +30,11 @@ class _Params(C.Structure):
                [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64)]
 
 
+class _Layout(C.Structure):
+    _fields_ = [(f, C.c_uint32) for f in ("n_slots", "n_levels", "max_width", "max_sources", "n_bootstrap", "n_keyswitch",
+                                          "n_inputs", "n_outputs")]
+
+
 class _ProgramDesc(C.Structure):
     _fields_ = [("n_inputs", C.c_uint32), ("n_instr", C.c_uint32), ("n_terms", C.c_uint32),
                 ("n_outputs", C.c_uint32),
@@ -41,7 +45,11 @@ class _ProgramDesc(C.Structure):
 
 @dataclass(frozen=True)
 class Params:
-    """Cryptographic parameter set.  P1024 is BASELINE.md's synthetic set."""
+    """Cryptographic parameter set.  The shape defaults to BASELINE.md's synthetic set (n=630 N=1024 k=1 l=3 beta=7
+    t=8 gamma=2).  A noise left at None becomes the smallest standard deviation that is 128-bit secure at its
+    dimension (`security.sigma_min`); anything lower is an explicit choice -- `reduced_noise()` is the benchmark
+    setting (2^-40 q, NOT secure), `params.P1024` the benchmark set built with it, `params.choose_params` the
+    selector that returns secure AND correct sets."""
     n: int = 630
     log_n_poly: int = 10
     k: int = 1
@@ -50,8 +58,19 @@ class Params:
     t_ksk: int = 8
     gamma_ksk: int = 2
     p_msg: int = 15
-    sigma_lwe: int = 1 << 6       # 2^-40 of q: reduced noise, see DESIGN.md "Noise"
-    sigma_glwe: int = 1 << 6
+    sigma_lwe: int | None = None      # key-switching-key noise, absolute units of 1/q
+    sigma_glwe: int | None = None     # bootstrapping-key and fresh-input noise
+
+    def __post_init__(self):
+        if self.sigma_lwe is None:
+            object.__setattr__(self, "sigma_lwe", sigma_min(self.n))
+        if self.sigma_glwe is None:
+            object.__setattr__(self, "sigma_glwe", sigma_min(self.k * (1 << self.log_n_poly)))
+
+    def reduced_noise(self, sigma: int = 1 << 6):
+        """The same shape with both noises at `sigma` (default 2^6 = 2^-40 q): throughput benchmarks and parity tests
+        only -- far below what any security level needs at these dimensions."""
+        return self.replace(sigma_lwe=sigma, sigma_glwe=sigma)
 
     @property
     def N(self):
@@ -117,6 +136,13 @@ def _load():
         "fbs_program_destroy": (None, [vp]),
         "fbs_program_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "fbs_eval": (i32, [vp, vp, vp, sz, vp]),
+        "fbs_eval_dev": (i32, [vp, vp, vp, sz, vp, vp]),
+        "fbs_program_layout": (i32, [vp, C.POINTER(_Layout)]),
+        "fbs_program_level": (i32, [vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+        "fbs_program_io_slots": (i32, [vp, vp, vp]),
+        "fbs_level_lincomb_dev": (i32, [vp, vp, u32, vp, sz, sz, sz, vp]),
+        "fbs_level_bootstrap_dev": (i32, [vp, vp, u32, vp, sz, sz, sz, sz, sz, vp, vp]),
+        "fbs_level_scatter_dev": (i32, [vp, vp, u32, vp, sz, sz, sz, vp, sz, sz, vp]),
         "fbs_profile_enable": (i32, [vp, i32]),
         "fbs_profile_read": (i32, [vp, C.POINTER(C.c_double * 3), C.POINTER(u64 * 3), i32]),
         "fbs_sync": (i32, [vp, vp]),
@@ -134,7 +160,8 @@ EXPORTED_SYMBOLS = (
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
     "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_destroy", "fbs_program_info",
-    "fbs_eval", "fbs_profile_enable", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
+    "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
+    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
 )
 
 lib = _load()
@@ -176,9 +203,19 @@ class Program:
         ctx._check(lib.fbs_program_load(ctx._h, C.byref(desc), tvset._h, C.byref(h)))
         self._h = h
         self.n_inputs, self.n_outputs = n_inputs, len(k[6])
-        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        lib.fbs_program_info(h, C.byref(a), C.byref(b), C.byref(c))
-        self.depth, self.max_width, self.n_bootstrap = a.value, b.value, c.value
+        lay = _Layout()
+        ctx._check(lib.fbs_program_layout(h, C.byref(lay)))
+        self.depth, self.max_width, self.n_bootstrap = lay.n_levels, lay.max_width, lay.n_bootstrap
+        self.n_slots, self.n_keyswitch, self.max_sources = lay.n_slots, lay.n_keyswitch, lay.max_sources
+        self.in_slot = np.empty(self.n_inputs, np.uint32)
+        self.out_slot = np.empty(self.n_outputs, np.int64)
+        ctx._check(lib.fbs_program_io_slots(h, _ptr(self.in_slot), _ptr(self.out_slot)))
+        self.level_width, self.level_sources = [], []
+        for L in range(self.depth):
+            a, b = C.c_uint32(), C.c_uint32()
+            ctx._check(lib.fbs_program_level(h, L, C.byref(a), C.byref(b)))
+            self.level_width.append(a.value)
+            self.level_sources.append(b.value)
 
     def eval(self, in_cts, T):
         ctw = self.ctx.params.ct_words
@@ -187,16 +224,38 @@ class Program:
         self.ctx._check(lib.fbs_eval(self.ctx._h, self._h, _ptr(in_cts), T, _ptr(out)))
         return out
 
-    def __del__(self):
+    # device-pointer entry points (ints from torch.Tensor.data_ptr()); asynchronous on `stream`, no host copies
+    def eval_dev(self, d_in, T, d_out, stream=0):
+        self.ctx._check(lib.fbs_eval_dev(self.ctx._h, self._h, d_in or None, T, d_out or None, stream or None))
+
+    def level_lincomb_dev(self, level, d_wires, T, s_begin, s_count, stream=0):
+        self.ctx._check(lib.fbs_level_lincomb_dev(self.ctx._h, self._h, level, d_wires, T, s_begin, s_count, stream or None))
+
+    def level_bootstrap_dev(self, level, d_wires, T, s_begin, s_count, f_begin, f_end, d_rows=0, stream=0):
+        self.ctx._check(lib.fbs_level_bootstrap_dev(self.ctx._h, self._h, level, d_wires, T, s_begin, s_count, f_begin, f_end,
+                                                    d_rows or None, stream or None))
+
+    def level_scatter_dev(self, level, d_wires, T, s_begin, s_count, d_rows, f_begin, f_end, stream=0):
+        self.ctx._check(lib.fbs_level_scatter_dev(self.ctx._h, self._h, level, d_wires, T, s_begin, s_count, d_rows, f_begin,
+                                                  f_end, stream or None))
+
+    def close(self):
         if getattr(self, "_h", None) and self.ctx._h and lib is not None:
             lib.fbs_program_destroy(self._h)
-            self._h = None
+        self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 class Context:
     """One GPU, one parameter set, one key set."""
 
-    def __init__(self, params: Params = Params(), seed: int = 1, device: int = 0, keygen: bool = True):
+    def __init__(self, params: Params, seed: int | None = None, device: int = 0, keygen: bool = True):
+        """seed: all key material and encryption randomness derive from it; None draws one from os.urandom
+        (tests and benchmarks pass a constant so that the CPU oracle can be keyed identically)."""
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")
         self.params = params
         self.seed = seed
         self._h = C.c_void_p()

@@ -111,12 +111,13 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     const size_t f_want = (size_t)blockIdx.x * FPW + sub;
     const bool live = f_want < a.count;
     const size_t f = live ? f_want : a.count - 1;
-    const size_t gate = f / a.gv.s_count;
+    size_t gate, ms_row;
+    gate_of(a.gv, f, &gate, &ms_row);
     // ids that arrive in device memory cannot be validated by the host: an id past the set reads table 0, never past
     // the end of the buffer
     uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
     if (table >= a.n_tables) table = 0;
-    const uint32_t *ms = a.ms + f * (a.n + 1);
+    const uint32_t *ms = a.ms + ms_row * (a.n + 1);
     const uint64_t *tv = a.tvs + (size_t)table * N;
     const uint32_t rows = 2 * a.l;
 
@@ -316,7 +317,17 @@ int dev_upload_keys(fbs_ctx *ctx) {
         FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, N * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_bsk_hat, bsk_words * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ksk, ksk_rows * ctx->ksk_stride * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_ks_corr, (size_t)ctx->ksk_stride * 8));
     }
+    // (B/2) * sum of all key rows: what turns the unsigned bit fields of the key-switch kernels into balanced digits
+    std::vector<uint64_t> corr(ctx->ksk_stride, 0);
+    {
+        std::vector<unsigned __int128> sum(p.n + 1, 0);
+        for (size_t r = 0; r < ksk_rows; r++)
+            for (uint32_t i = 0; i <= p.n; i++) sum[i] += ctx->ksk[r * (p.n + 1) + i];
+        for (uint32_t i = 0; i <= p.n; i++) corr[i] = fq_mul((uint64_t)(sum[i] % FQ), 1ull << (p.gamma_ksk - 1));
+    }
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_ks_corr, corr.data(), corr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_fwd, fwd_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
     FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_inv, inv_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
     FBS_HIP(ctx, hipMemsetAsync(ctx->d_ksk, 0, ksk_rows * ctx->ksk_stride * 8, ctx->stream));
@@ -346,7 +357,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     a.beta = p.beta_bsk;
     a.ct_words = ctx->D + 1;
     a.n_tables = std::max(1u, tv->n_tables);
-    const size_t count = (size_t)gv.n_gates * gv.s_count;
+    const size_t count = gv.count;
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");
     a.count = count;

@@ -25,25 +25,30 @@ int set_error(const fbs_ctx *ctx, int code, const std::string &msg) {
 // ---------------------------------------------------------------------------------------------
 struct LincombStage {
     uint32_t n_out = 0;
-    uint32_t *d_dst = nullptr, *d_term_off = nullptr, *d_srcs = nullptr;
+    uint32_t *d_dst = nullptr, *d_term_off = nullptr, *d_srcs = nullptr;   // wire SLOTS
     uint64_t *d_coefs = nullptr, *d_consts = nullptr;
 };
+// Bootstraps of one level, sorted by source wire.  Gates that read the same wire (the reference's one-gate-one-bootstrap
+// lowering emits several tables per linear combination, fbs_mapper/map_to_fbs.py:41-45, and its CSE only merges
+// identical tables, fbs_mapper/fbs_exec_env.py:93-100) share one key switch + modulus switch.
 struct BootStage {
-    uint32_t n_gates = 0;
-    uint32_t *d_src = nullptr, *d_dst = nullptr, *d_table = nullptr;
+    uint32_t n_gates = 0, n_sources = 0;
+    uint32_t *d_src_slot = nullptr;    // [n_sources] wire slot of each distinct source
+    uint32_t *d_source_of = nullptr;   // [n_gates]   index into d_src_slot
+    uint32_t *d_dst = nullptr, *d_table = nullptr;   // [n_gates]
+    std::vector<uint32_t> source_of;   // host copy: which key switches a slice of the level needs
 };
 struct fbs_prog {
     fbs_ctx *ctx = nullptr;
     const fbs_tvset *tv = nullptr;
-    uint32_t n_inputs = 0, n_instr = 0, n_outputs = 0, n_wires = 0;
-    uint32_t depth = 0, max_width = 0, n_bootstrap = 0;
-    std::vector<int64_t> out_wire;
+    uint32_t n_inputs = 0, n_instr = 0, n_outputs = 0, n_wires = 0, n_slots = 0;
+    uint32_t depth = 0, max_width = 0, max_sources = 0, n_bootstrap = 0, n_keyswitch = 0;
+    std::vector<uint32_t> in_slot;    // [n_inputs]
+    std::vector<int64_t> out_slot;    // [n_outputs]  slot, or -1-c for the constant c
     // schedule: for level L = 0..depth: lincomb stages (dependency order), then the bootstraps of level L+1
     std::vector<std::vector<LincombStage>> lin;   // [depth+1][sub]
     std::vector<BootStage> boot;                  // [depth]  (boot[L] = bootstraps of level L+1)
     std::vector<void *> allocations;
-    uint64_t *d_wires = nullptr;
-    size_t wires_T = 0;
 };
 
 template <typename T>
@@ -70,12 +75,43 @@ static hipStream_t pick(fbs_ctx *ctx, void *stream) { return stream ? (hipStream
 
 static int ensure_ms(fbs_ctx *ctx, size_t count) {
     if (count <= ctx->ms_capacity) return FBS_OK;
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // kernels may still read the old buffer
     if (ctx->d_ms) (void)hipFree(ctx->d_ms);
     ctx->d_ms = nullptr;
     ctx->ms_capacity = 0;
     FBS_HIP(ctx, hipMalloc(&ctx->d_ms, count * (ctx->p.n + 1) * sizeof(uint32_t)));
     ctx->ms_capacity = count;
     return FBS_OK;
+}
+
+// Cross-stream ordering of the per-context scratch (d_ms, d_idx, d_wires): a call on stream `s` first waits for the last
+// call that used the scratch on ANOTHER stream; calls on one stream are ordered by the stream itself.
+static int scratch_wait(fbs_ctx *ctx, hipStream_t s) {
+    if (ctx->scratch_used && ctx->scratch_stream != s) FBS_HIP(ctx, hipStreamWaitEvent(s, ctx->scratch_event, 0));
+    return FBS_OK;
+}
+static int scratch_done(fbs_ctx *ctx, hipStream_t s) {
+    FBS_HIP(ctx, hipEventRecord(ctx->scratch_event, s));
+    ctx->scratch_stream = s;
+    ctx->scratch_used = true;
+    return FBS_OK;
+}
+
+// the plain batch: gate g = ciphertext g, one sample each
+static GateView batch_view(const uint64_t *in, uint64_t *out, const uint32_t *table_ids, size_t count) {
+    GateView gv{};
+    gv.in_base = in;
+    gv.out_base = out;
+    gv.table_ids = table_ids;
+    gv.T = 1;
+    gv.s_begin = 0;
+    gv.s_count = 1;
+    gv.f_begin = 0;
+    gv.count = count;
+    gv.ks_begin = 0;
+    gv.ks_count = count;
+    gv.n_gates = (uint32_t)count;
+    return gv;
 }
 
 extern "C" {
@@ -124,6 +160,11 @@ int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx 
     // a caller that passes stream = NULL while using torch tensors still gets correct ordering
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault);
     if (e != hipSuccess) return set_error(nullptr, FBS_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    e = hipEventCreateWithFlags(&ctx->scratch_event, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        return set_error(nullptr, FBS_E_DEVICE, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
     *out = ctx.release();
     return FBS_OK;
 }
@@ -132,9 +173,11 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
-                    (void *)ctx->d_idx})
+    if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
+                    (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
+    if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
     for (auto &v : ctx->prof.pending)
         for (auto &pr : v) {
             (void)hipEventDestroy(pr.first);
@@ -214,10 +257,14 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
             return set_error(ctx, rc, "table " + std::to_string(t) + " of length " + std::to_string(table_off[t + 1] - table_off[t]) +
                                           " is not evaluable by one bootstrap at p = " + std::to_string(ctx->p.p_msg));
     }
-    FBS_HIP(ctx, hipMalloc(&tv->d_tvs, host.size() * 8));
-    FBS_HIP(ctx, hipMalloc(&tv->d_post, tv->post.size() * 8));
-    FBS_HIP(ctx, hipMemcpy(tv->d_tvs, host.data(), host.size() * 8, hipMemcpyHostToDevice));
-    FBS_HIP(ctx, hipMemcpy(tv->d_post, tv->post.data(), tv->post.size() * 8, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(&tv->d_tvs, host.size() * 8);
+    if (e == hipSuccess) e = hipMalloc(&tv->d_post, tv->post.size() * 8);
+    if (e == hipSuccess) e = hipMemcpy(tv->d_tvs, host.data(), host.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tv->d_post, tv->post.data(), tv->post.size() * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fbs_tvset_destroy(tv.release());   // frees whichever buffer was obtained
+        return set_error(ctx, FBS_E_DEVICE, std::string("test-vector upload: ") + hipGetErrorString(e));
+    }
     *out = tv.release();
     return FBS_OK;
 }
@@ -248,18 +295,14 @@ int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large");
     rc = ensure_ms(ctx, count);
     if (rc != FBS_OK) return rc;
-    GateView gv{};
-    gv.in_base = d_cts_in;
-    gv.out_base = d_cts_out;
-    gv.table_ids = d_table_ids;
-    gv.T = 1;
-    gv.s_begin = 0;
-    gv.s_count = 1;
-    gv.n_gates = (uint32_t)count;
+    const GateView gv = batch_view(d_cts_in, d_cts_out, d_table_ids, count);
     hipStream_t s = pick(ctx, stream);
+    if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
     rc = dev_keyswitch(ctx, gv, ctx->d_ms, s);
     if (rc != FBS_OK) return rc;
-    return dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+    rc = dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+    if (rc != FBS_OK) return rc;
+    return scratch_done(ctx, s);
 }
 
 int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_in, const uint32_t *table_ids, size_t count,
@@ -308,14 +351,14 @@ int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_i
 }
 
 // ---------------------------------------------------------------------------------------------
-// wire-slot building blocks (the multi-GPU host drives these level by level)
+// wire-slot building blocks with HOST index arrays (convenience: each call stages its indices through a
+// per-context buffer and waits for the copy; hosts that step a loaded program use the fbs_level_* calls below,
+// whose index arrays were uploaded once by fbs_program_load)
 // ---------------------------------------------------------------------------------------------
 static int ensure_idx(fbs_ctx *ctx, size_t words) {
     if (words <= ctx->idx_capacity) return FBS_OK;
-    if (ctx->d_idx) {
-        FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_idx);
-    }
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
+    if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     ctx->d_idx = nullptr;
     ctx->idx_capacity = 0;
     size_t cap = std::max<size_t>(words, 1 << 16);
@@ -331,12 +374,13 @@ int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, c
     if (n_out == 0 || T == 0) return FBS_OK;
     if (!d_wires || !dst || !term_off || !consts) return set_error(ctx, FBS_E_INVALID, "null argument");
     const uint32_t n_terms = term_off[n_out];
+    if (n_terms && (!srcs || !coefs)) return set_error(ctx, FBS_E_INVALID, "null argument");
     // staging: [dst n_out][term_off n_out+1][srcs n_terms] as u32, then coefs and consts as u64
     size_t u32_words = (size_t)n_out + (n_out + 1) + n_terms;
     u32_words = (u32_words + 1) & ~(size_t)1;
     size_t total = u32_words + 2 * ((size_t)n_terms + n_out);
     hipStream_t s = pick(ctx, stream);
-    FBS_HIP(ctx, hipStreamSynchronize(s));   // the staging buffer may still be read by the previous call
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // the staging buffer may still be read
     rc = ensure_idx(ctx, total);
     if (rc != FBS_OK) return rc;
     std::vector<uint32_t> stage(total, 0);
@@ -350,7 +394,9 @@ int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, c
     FBS_HIP(ctx, hipStreamSynchronize(s));   // `stage` is pageable host memory going out of scope
     const uint32_t *d_dst = ctx->d_idx, *d_off = ctx->d_idx + n_out, *d_srcs = ctx->d_idx + 2 * (size_t)n_out + 1;
     const uint64_t *d_f = reinterpret_cast<const uint64_t *>(ctx->d_idx + u32_words);
-    return dev_lincomb(ctx, d_wires, T, n_out, d_dst, d_off, d_srcs, d_f, d_f + n_terms, s);
+    rc = dev_lincomb(ctx, d_wires, T, 0, T, n_out, d_dst, d_off, d_srcs, d_f, d_f + n_terms, s);
+    if (rc != FBS_OK) return rc;
+    return scratch_done(ctx, s);
 }
 
 int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires, size_t T, uint32_t n_gates,
@@ -361,9 +407,11 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
     if (!tv || !d_wires || !src || !dst || !table_ids) return set_error(ctx, FBS_E_INVALID, "null argument");
     if (s_end > T || s_begin > s_end) return set_error(ctx, FBS_E_INVALID, "bad sample range");
     if (n_gates == 0 || s_begin == s_end) return FBS_OK;
+    for (uint32_t g = 0; g < n_gates; g++)
+        if (table_ids[g] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
     const size_t count = (size_t)n_gates * (s_end - s_begin);
     hipStream_t s = pick(ctx, stream);
-    FBS_HIP(ctx, hipStreamSynchronize(s));
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
     rc = ensure_idx(ctx, 3 * (size_t)n_gates);
     if (rc != FBS_OK) return rc;
     rc = ensure_ms(ctx, count);
@@ -372,8 +420,6 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
     std::memcpy(stage.data(), src, (size_t)n_gates * 4);
     std::memcpy(stage.data() + n_gates, dst, (size_t)n_gates * 4);
     std::memcpy(stage.data() + 2 * (size_t)n_gates, table_ids, (size_t)n_gates * 4);
-    for (uint32_t g = 0; g < n_gates; g++)
-        if (table_ids[g] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
     FBS_HIP(ctx, hipMemcpyAsync(ctx->d_idx, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, s));
     FBS_HIP(ctx, hipStreamSynchronize(s));
     GateView gv{};
@@ -385,10 +431,16 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
     gv.T = T;
     gv.s_begin = s_begin;
     gv.s_count = s_end - s_begin;
+    gv.f_begin = 0;
+    gv.count = count;
+    gv.ks_begin = 0;
+    gv.ks_count = count;
     gv.n_gates = n_gates;
     rc = dev_keyswitch(ctx, gv, ctx->d_ms, s);
     if (rc != FBS_OK) return rc;
-    return dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+    rc = dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
+    if (rc != FBS_OK) return rc;
+    return scratch_done(ctx, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -406,11 +458,11 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *t
     prog->n_instr = d->n_instr;
     prog->n_outputs = d->n_outputs;
     prog->n_wires = d->n_inputs + d->n_instr;
-    prog->out_wire.assign(d->out_wire, d->out_wire + d->n_outputs);
+    const uint32_t n_wires = prog->n_wires;
 
     // levels: inputs 0, LinearProd = max over sources, Bootstrap = source + 1
-    std::vector<uint32_t> level(prog->n_wires, 0), sub(prog->n_wires, 0);
-    std::vector<uint8_t> is_lin(prog->n_wires, 0);
+    std::vector<uint32_t> level(n_wires, 0), sub(n_wires, 0);
+    std::vector<uint8_t> is_lin(n_wires, 0);
     for (uint32_t i = 0; i < d->n_instr; i++) {
         const uint32_t w = d->n_inputs + i;
         if (d->kind[i] == 0) {
@@ -439,9 +491,69 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *t
         }
     }
     for (uint32_t o = 0; o < d->n_outputs; o++)
-        if (d->out_wire[o] >= (int64_t)prog->n_wires) return set_error(ctx, FBS_E_INVALID, "output wire out of range");
+        if (d->out_wire[o] >= (int64_t)n_wires) return set_error(ctx, FBS_E_INVALID, "output wire out of range");
 
     const uint32_t depth = prog->depth;
+    // ---- stages in execution order: for each level its lincomb sub-stages, then its bootstraps ----------------
+    std::vector<uint32_t> n_sub(depth + 1, 0);
+    for (uint32_t w = d->n_inputs; w < n_wires; w++)
+        if (is_lin[w]) n_sub[level[w]] = std::max(n_sub[level[w]], sub[w] + 1);
+    std::vector<uint32_t> lin_time0(depth + 1, 0), boot_time(depth, 0);
+    uint32_t n_stages = 0;
+    for (uint32_t L = 0; L <= depth; L++) {
+        lin_time0[L] = n_stages;
+        n_stages += n_sub[L];
+        if (L < depth) boot_time[L] = n_stages++;
+    }
+    auto def_time = [&](uint32_t w) -> int64_t {
+        if (w < d->n_inputs) return -1;
+        return is_lin[w] ? (int64_t)lin_time0[level[w]] + sub[w] : (int64_t)boot_time[level[w] - 1];
+    };
+    // ---- liveness: a wire keeps its slot until the stage of its last reader has run (outputs: for ever) ---------
+    const int64_t FOREVER = (int64_t)n_stages + 1;
+    std::vector<int64_t> last(n_wires);
+    for (uint32_t w = 0; w < n_wires; w++) last[w] = def_time(w);
+    for (uint32_t i = 0; i < d->n_instr; i++) {
+        const uint32_t w = d->n_inputs + i;
+        const int64_t t = def_time(w);
+        if (d->kind[i] == 0) {
+            for (uint32_t k = d->arg0[i]; k < d->arg0[i] + d->arg1[i]; k++) last[d->term_src[k]] = std::max(last[d->term_src[k]], t);
+        } else {
+            last[d->arg0[i]] = std::max(last[d->arg0[i]], t);
+        }
+    }
+    for (uint32_t o = 0; o < d->n_outputs; o++)
+        if (d->out_wire[o] >= 0) last[d->out_wire[o]] = FOREVER;
+    std::vector<std::vector<uint32_t>> born(n_stages + 1), dies(n_stages + 1);   // index = time + 1
+    for (uint32_t w = 0; w < n_wires; w++) {
+        born[def_time(w) + 1].push_back(w);
+        if (last[w] != FOREVER) dies[last[w] + 1].push_back(w);
+    }
+    std::vector<uint32_t> slot(n_wires, 0), free_slots;   // free_slots: min-heap, lowest slot first (compact buffer)
+    auto cmp = std::greater<uint32_t>();
+    uint32_t n_slots = 0;
+    for (uint32_t t = 0; t <= n_stages; t++) {
+        for (uint32_t w : born[t]) {
+            if (free_slots.empty()) {
+                slot[w] = n_slots++;
+            } else {
+                std::pop_heap(free_slots.begin(), free_slots.end(), cmp);
+                slot[w] = free_slots.back();
+                free_slots.pop_back();
+            }
+        }
+        // freed only now: a slot is never rewritten by the stage that reads it last
+        for (uint32_t w : dies[t]) {
+            free_slots.push_back(slot[w]);
+            std::push_heap(free_slots.begin(), free_slots.end(), cmp);
+        }
+    }
+    prog->n_slots = std::max(1u, n_slots);
+    prog->in_slot.assign(slot.begin(), slot.begin() + d->n_inputs);
+    prog->out_slot.resize(d->n_outputs);
+    for (uint32_t o = 0; o < d->n_outputs; o++) prog->out_slot[o] = d->out_wire[o] >= 0 ? (int64_t)slot[d->out_wire[o]] : d->out_wire[o];
+
+    // ---- stage tables (wire slots, not wire ids) ---------------------------------------------------------------
     prog->lin.resize(depth + 1);
     prog->boot.resize(depth);
     struct LinHost {
@@ -449,60 +561,59 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *t
         std::vector<uint64_t> coefs, consts;
     };
     std::vector<std::vector<LinHost>> lh(depth + 1);
-    struct BootHost {
-        std::vector<uint32_t> src, dst, tab;
+    struct Gate {
+        uint32_t src, dst, tab;
     };
-    std::vector<BootHost> bh(depth);
+    std::vector<std::vector<Gate>> bh(depth);
     for (uint32_t i = 0; i < d->n_instr; i++) {
         const uint32_t w = d->n_inputs + i;
         if (d->kind[i] == 0) {
             auto &stages = lh[level[w]];
             if (stages.size() <= sub[w]) stages.resize(sub[w] + 1);
             LinHost &h = stages[sub[w]];
-            h.dst.push_back(w);
+            h.dst.push_back(slot[w]);
             for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
-                h.srcs.push_back(d->term_src[t]);
+                h.srcs.push_back(slot[d->term_src[t]]);
                 h.coefs.push_back(coef_bits(d->term_coef[t]));
             }
             h.off.push_back((uint32_t)h.srcs.size());
             h.consts.push_back(fq_mul(fq_from_i64(d->const_coef[i]), 2 * ctx->delta_half));
         } else {
-            BootHost &b = bh[level[w] - 1];
-            b.src.push_back(d->arg0[i]);
-            b.dst.push_back(w);
-            b.tab.push_back(d->arg1[i]);
+            bh[level[w] - 1].push_back({d->arg0[i], slot[w], d->arg1[i]});
         }
     }
     for (uint32_t L = 0; L <= depth; L++) {
         for (LinHost &h : lh[L]) {
-            if (h.dst.empty()) continue;
-            // k_lincomb's grid.y carries the output index: split very wide stages
-            for (size_t a = 0; a < h.dst.size(); a += 32768) {
-                size_t b = std::min(h.dst.size(), a + 32768);
-                LincombStage st;
-                st.n_out = (uint32_t)(b - a);
-                std::vector<uint32_t> dst(h.dst.begin() + a, h.dst.begin() + b), off;
-                const uint32_t t0 = h.off[a];
-                for (size_t g = a; g <= b; g++) off.push_back(h.off[g] - t0);
-                std::vector<uint32_t> srcs(h.srcs.begin() + t0, h.srcs.begin() + h.off[b]);
-                std::vector<uint64_t> coefs(h.coefs.begin() + t0, h.coefs.begin() + h.off[b]);
-                std::vector<uint64_t> consts(h.consts.begin() + a, h.consts.begin() + b);
-                if ((rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), off, &st.d_term_off)) ||
-                    (rc = to_device(ctx, prog.get(), srcs, &st.d_srcs)) || (rc = to_device(ctx, prog.get(), coefs, &st.d_coefs)) ||
-                    (rc = to_device(ctx, prog.get(), consts, &st.d_consts)))
-                    return rc;
-                prog->lin[L].push_back(st);
-            }
+            LincombStage st;
+            st.n_out = (uint32_t)h.dst.size();
+            if (st.n_out &&
+                ((rc = to_device(ctx, prog.get(), h.dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), h.off, &st.d_term_off)) ||
+                 (rc = to_device(ctx, prog.get(), h.srcs, &st.d_srcs)) || (rc = to_device(ctx, prog.get(), h.coefs, &st.d_coefs)) ||
+                 (rc = to_device(ctx, prog.get(), h.consts, &st.d_consts))))
+                return rc;
+            prog->lin[L].push_back(st);   // kept even when empty: stage times above count every sub-stage
         }
     }
     for (uint32_t L = 0; L < depth; L++) {
+        std::vector<Gate> &gates = bh[L];
+        std::stable_sort(gates.begin(), gates.end(), [](const Gate &x, const Gate &y) { return x.src < y.src; });
         BootStage st;
-        st.n_gates = (uint32_t)bh[L].src.size();
+        st.n_gates = (uint32_t)gates.size();
+        std::vector<uint32_t> src_slot, dst, tab;
+        for (size_t g = 0; g < gates.size(); g++) {
+            if (g == 0 || gates[g].src != gates[g - 1].src) src_slot.push_back(slot[gates[g].src]);
+            st.source_of.push_back((uint32_t)src_slot.size() - 1);
+            dst.push_back(gates[g].dst);
+            tab.push_back(gates[g].tab);
+        }
+        st.n_sources = (uint32_t)src_slot.size();
         prog->max_width = std::max(prog->max_width, st.n_gates);
-        if ((rc = to_device(ctx, prog.get(), bh[L].src, &st.d_src)) || (rc = to_device(ctx, prog.get(), bh[L].dst, &st.d_dst)) ||
-            (rc = to_device(ctx, prog.get(), bh[L].tab, &st.d_table)))
+        prog->max_sources = std::max(prog->max_sources, st.n_sources);
+        prog->n_keyswitch += st.n_sources;
+        if ((rc = to_device(ctx, prog.get(), src_slot, &st.d_src_slot)) || (rc = to_device(ctx, prog.get(), st.source_of, &st.d_source_of)) ||
+            (rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), tab, &st.d_table)))
             return rc;
-        prog->boot[L] = st;
+        prog->boot[L] = std::move(st);
     }
     *out = prog.release();
     return FBS_OK;
@@ -512,7 +623,6 @@ void fbs_program_destroy(fbs_prog *prog) {
     if (!prog) return;
     if (prog->ctx) (void)hipSetDevice(prog->ctx->device);
     for (void *p : prog->allocations) (void)hipFree(p);
-    if (prog->d_wires) (void)hipFree(prog->d_wires);
     delete prog;
 }
 
@@ -524,6 +634,170 @@ int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_wid
     return FBS_OK;
 }
 
+int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) {
+    if (!prog || !out) return FBS_E_INVALID;
+    out->n_slots = prog->n_slots;
+    out->n_levels = prog->depth;
+    out->max_width = prog->max_width;
+    out->max_sources = prog->max_sources;
+    out->n_bootstrap = prog->n_bootstrap;
+    out->n_keyswitch = prog->n_keyswitch;
+    out->n_inputs = prog->n_inputs;
+    out->n_outputs = prog->n_outputs;
+    return FBS_OK;
+}
+
+int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources) {
+    if (!prog || level >= prog->depth) return FBS_E_INVALID;
+    if (n_gates) *n_gates = prog->boot[level].n_gates;
+    if (n_sources) *n_sources = prog->boot[level].n_sources;
+    return FBS_OK;
+}
+
+int fbs_program_io_slots(const fbs_prog *prog, uint32_t *in_slot, int64_t *out_slot) {
+    if (!prog) return FBS_E_INVALID;
+    if (in_slot) std::copy(prog->in_slot.begin(), prog->in_slot.end(), in_slot);
+    if (out_slot) std::copy(prog->out_slot.begin(), prog->out_slot.end(), out_slot);
+    return FBS_OK;
+}
+
+// ---- one level at a time, device-resident wires, nothing but kernel launches on `stream` ------------------------
+static int check_level_call(fbs_ctx *ctx, const fbs_prog *prog, const uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count) {
+    int rc = check_ready(ctx, prog ? prog->tv : nullptr);
+    if (rc != FBS_OK) return rc;
+    if (!prog || prog->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "program belongs to another context");
+    if (!d_wires) return set_error(ctx, FBS_E_INVALID, "null argument");
+    if (s_begin + s_count > T) return set_error(ctx, FBS_E_INVALID, "bad sample range");
+    return FBS_OK;
+}
+
+int fbs_level_lincomb_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
+                          size_t s_count, void *stream) {
+    int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
+    if (rc != FBS_OK) return rc;
+    if (level > prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
+    hipStream_t s = pick(ctx, stream);
+    for (const LincombStage &st : prog->lin[level]) {
+        rc = dev_lincomb(ctx, d_wires, T, s_begin, s_count, st.n_out, st.d_dst, st.d_term_off, st.d_srcs, st.d_coefs, st.d_consts, s);
+        if (rc != FBS_OK) return rc;
+    }
+    return FBS_OK;
+}
+
+int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
+                            size_t s_count, size_t f_begin, size_t f_end, uint64_t *d_rows, void *stream) {
+    int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
+    if (rc != FBS_OK) return rc;
+    if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
+    const BootStage &b = prog->boot[level];
+    if (f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad bootstrap range");
+    if (f_begin == f_end) return FBS_OK;   // (covers s_count == 0)
+    // the key switches this slice needs: the (source, sample) pairs of its gates, as ONE flattened range.  Gates are
+    // sorted by source, so only the first and the last gate of the slice can be cut short in the sample direction, and
+    // only while no other gate of the slice shares their source.
+    const size_t g0 = f_begin / s_count, s0 = f_begin % s_count;
+    const size_t g1 = (f_end - 1) / s_count, s1 = (f_end - 1) % s_count + 1;
+    const size_t u0 = b.source_of[g0], u1 = b.source_of[g1];
+    const bool first_shared = g1 > g0 && b.source_of[g0 + 1] == u0;
+    const bool last_shared = g1 > g0 && b.source_of[g1 - 1] == u1;
+    GateView gv{};
+    gv.in_base = d_wires;
+    gv.out_base = d_wires;
+    gv.src_slot = b.d_src_slot;
+    gv.dst_slot = b.d_dst;
+    gv.table_ids = b.d_table;
+    gv.source_of = b.d_source_of;
+    gv.out_rows = d_rows;
+    gv.T = T;
+    gv.s_begin = s_begin;
+    gv.s_count = s_count;
+    gv.f_begin = f_begin;
+    gv.count = f_end - f_begin;
+    gv.ks_begin = u0 * s_count + (first_shared ? 0 : s0);
+    gv.ks_count = u1 * s_count + (last_shared ? s_count : s1) - gv.ks_begin;
+    gv.n_gates = b.n_gates;
+    rc = ensure_ms(ctx, gv.ks_count);
+    if (rc != FBS_OK) return rc;
+    hipStream_t s = pick(ctx, stream);
+    if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
+    if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+    if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+    return scratch_done(ctx, s);
+}
+
+int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
+                          size_t s_count, const uint64_t *d_rows, size_t f_begin, size_t f_end, void *stream) {
+    int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
+    if (rc != FBS_OK) return rc;
+    if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
+    const BootStage &b = prog->boot[level];
+    if (!d_rows || f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad row range");
+    return dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, pick(ctx, stream));
+}
+
+static int run_levels(fbs_ctx *ctx, const fbs_prog *prog, uint64_t *d_wires, size_t T, size_t s_count, hipStream_t s) {
+    int rc;
+    for (uint32_t L = 0; L <= prog->depth; L++) {
+        if ((rc = fbs_level_lincomb_dev(ctx, prog, L, d_wires, T, 0, s_count, s)) != FBS_OK) return rc;
+        if (L == prog->depth) break;
+        const size_t total = (size_t)prog->boot[L].n_gates * s_count;
+        if ((rc = fbs_level_bootstrap_dev(ctx, prog, L, d_wires, T, 0, s_count, 0, total, nullptr, s)) != FBS_OK) return rc;
+    }
+    return FBS_OK;
+}
+
+// Samples are independent through the whole program: evaluate in chunks whose wire slots fit in HBM.  The wire buffer
+// belongs to the context and is shared by all of its programs (it only ever grows).
+static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *chunk) {
+    const size_t ctw = ctx->D + 1;
+    const size_t per_sample = (size_t)prog->n_slots * ctw * 8 + (size_t)std::max(1u, prog->max_sources) * (ctx->p.n + 1) * 4;
+    size_t free_b = 0, total_b = 0;
+    FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
+    const size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4;
+    const size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / per_sample));
+    const size_t words = Tc * (size_t)prog->n_slots * ctw;
+    if (ctx->wires_capacity < words) {
+        if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
+        if (ctx->d_wires) (void)hipFree(ctx->d_wires);
+        ctx->d_wires = nullptr;
+        ctx->wires_capacity = 0;
+        FBS_HIP(ctx, hipMalloc(&ctx->d_wires, words * 8));
+        ctx->wires_capacity = words;
+    }
+    int rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_sources) * Tc);
+    if (rc != FBS_OK) return rc;
+    *chunk = Tc;
+    return FBS_OK;
+}
+
+static uint64_t trivial_body(const fbs_ctx *ctx, int64_t out_slot) { return fq_mul(fq_from_i64(-1 - out_slot), 2 * ctx->delta_half); }
+
+int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, uint64_t *d_out, void *stream) {
+    int rc = check_ready(ctx, prog ? prog->tv : nullptr);
+    if (rc != FBS_OK) return rc;
+    if (!prog || prog->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "program belongs to another context");
+    if (T == 0) return FBS_OK;
+    if ((prog->n_inputs && !d_in) || (prog->n_outputs && !d_out)) return set_error(ctx, FBS_E_INVALID, "null argument");
+    const size_t ctw = ctx->D + 1;
+    hipStream_t s = pick(ctx, stream);
+    size_t Tc = 0;
+    if ((rc = reserve_wires(ctx, prog, T, &Tc)) != FBS_OK) return rc;
+    if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
+    for (size_t s0 = 0; s0 < T; s0 += Tc) {
+        const size_t tc = std::min(Tc, T - s0);
+        for (uint32_t i = 0; i < prog->n_inputs; i++)
+            FBS_HIP(ctx, hipMemcpyAsync(ctx->d_wires + (size_t)prog->in_slot[i] * Tc * ctw, d_in + ((size_t)i * T + s0) * ctw, tc * ctw * 8,
+                                        hipMemcpyDeviceToDevice, s));
+        if ((rc = run_levels(ctx, prog, ctx->d_wires, Tc, tc, s)) != FBS_OK) return rc;
+        for (uint32_t o = 0; o < prog->n_outputs; o++) {
+            const int64_t w = prog->out_slot[o];
+            rc = dev_copy_out(ctx, ctx->d_wires, Tc, 0, tc, w, w < 0 ? trivial_body(ctx, w) : 0, d_out + ((size_t)o * T + s0) * ctw, s);
+            if (rc != FBS_OK) return rc;
+        }
+    }
+    return scratch_done(ctx, s);
+}
+
 int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts) {
     int rc = check_ready(ctx, prog ? prog->tv : nullptr);
     if (rc != FBS_OK) return rc;
@@ -532,57 +806,22 @@ int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uin
     if ((prog->n_inputs && !in_cts) || (prog->n_outputs && !out_cts)) return set_error(ctx, FBS_E_INVALID, "null argument");
     const size_t ctw = ctx->D + 1;
     hipStream_t s = ctx->stream;
-
-    // samples are independent through the whole program: evaluate in chunks that fit in HBM
-    size_t free_b = 0, total_b = 0;
-    FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    const size_t per_sample = (size_t)prog->n_wires * ctw * 8 + (size_t)prog->max_width * (ctx->p.n + 1) * 4;
-    size_t have = free_b + prog->wires_T * (size_t)prog->n_wires * ctw * 8;
-    size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / std::max<size_t>(1, per_sample)));
-    if (prog->wires_T < Tc) {
-        if (prog->d_wires) (void)hipFree(prog->d_wires);
-        prog->d_wires = nullptr;
-        prog->wires_T = 0;
-        FBS_HIP(ctx, hipMalloc(&prog->d_wires, Tc * (size_t)prog->n_wires * ctw * 8));
-        prog->wires_T = Tc;
-    }
-    const size_t TW = prog->wires_T;   // sample stride of the wire buffer
-    rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_width) * std::min(Tc, T));
-    if (rc != FBS_OK) return rc;
-
+    size_t Tc = 0;
+    if ((rc = reserve_wires(ctx, prog, T, &Tc)) != FBS_OK) return rc;
+    if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
     for (size_t s0 = 0; s0 < T; s0 += Tc) {
         const size_t tc = std::min(Tc, T - s0);
         for (uint32_t i = 0; i < prog->n_inputs; i++)
-            FBS_HIP(ctx, hipMemcpyAsync(prog->d_wires + (size_t)i * TW * ctw, in_cts + ((size_t)i * T + s0) * ctw, tc * ctw * 8,
+            FBS_HIP(ctx, hipMemcpyAsync(ctx->d_wires + (size_t)prog->in_slot[i] * Tc * ctw, in_cts + ((size_t)i * T + s0) * ctw, tc * ctw * 8,
                                         hipMemcpyHostToDevice, s));
-        for (uint32_t L = 0; L <= prog->depth; L++) {
-            for (const LincombStage &st : prog->lin[L]) {
-                // grid.x = samples actually present in this chunk; the buffer stride stays TW
-                rc = dev_lincomb(ctx, prog->d_wires, TW, st.n_out, st.d_dst, st.d_term_off, st.d_srcs, st.d_coefs, st.d_consts, s);
-                if (rc != FBS_OK) return rc;
-            }
-            if (L == prog->depth) break;
-            const BootStage &b = prog->boot[L];
-            GateView gv{};
-            gv.in_base = prog->d_wires;
-            gv.out_base = prog->d_wires;
-            gv.src_slot = b.d_src;
-            gv.dst_slot = b.d_dst;
-            gv.table_ids = b.d_table;
-            gv.T = TW;
-            gv.s_begin = 0;
-            gv.s_count = tc;
-            gv.n_gates = b.n_gates;
-            if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return rc;
-            if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return rc;
-        }
+        if ((rc = run_levels(ctx, prog, ctx->d_wires, Tc, tc, s)) != FBS_OK) return rc;
         for (uint32_t o = 0; o < prog->n_outputs; o++) {
             uint64_t *dst = out_cts + ((size_t)o * T + s0) * ctw;
-            const int64_t w = prog->out_wire[o];
+            const int64_t w = prog->out_slot[o];
             if (w >= 0) {
-                FBS_HIP(ctx, hipMemcpyAsync(dst, prog->d_wires + (size_t)w * TW * ctw, tc * ctw * 8, hipMemcpyDeviceToHost, s));
+                FBS_HIP(ctx, hipMemcpyAsync(dst, ctx->d_wires + (size_t)w * Tc * ctw, tc * ctw * 8, hipMemcpyDeviceToHost, s));
             } else {
-                const uint64_t body = fq_mul(fq_from_i64(-1 - w), 2 * ctx->delta_half);   // trivial ciphertext of the constant
+                const uint64_t body = trivial_body(ctx, w);   // trivial ciphertext of the constant
                 for (size_t q = 0; q < tc; q++) {
                     std::memset(dst + q * ctw, 0, ctx->D * 8);
                     dst[q * ctw + ctx->D] = body;
@@ -591,7 +830,7 @@ int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uin
         }
         FBS_HIP(ctx, hipStreamSynchronize(s));
     }
-    return FBS_OK;
+    return scratch_done(ctx, s);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,14 +4,26 @@
 
 namespace fbs {
 
-__device__ __forceinline__ const uint64_t *gate_in(const GateView &gv, size_t f, uint32_t ct_words) {
-    size_t g = f / gv.s_count, s = gv.s_begin + f % gv.s_count;
-    size_t slot = gv.src_slot ? gv.src_slot[g] : g;
+// input ciphertext of key switch r of the launch (r < ks_count)
+__device__ __forceinline__ const uint64_t *ks_in(const GateView &gv, size_t r, uint32_t ct_words) {
+    const size_t fk = gv.ks_begin + r;
+    const size_t u = fk / gv.s_count, s = gv.s_begin + fk % gv.s_count;
+    const size_t slot = gv.src_slot ? gv.src_slot[u] : u;
     return gv.in_base + (slot * gv.T + s) * ct_words;
 }
-__device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t f, uint32_t ct_words) {
-    size_t g = f / gv.s_count, s = gv.s_begin + f % gv.s_count;
-    size_t slot = gv.dst_slot ? gv.dst_slot[g] : g;
+// bootstrap i of the launch (i < count): its gate, and the row of the modulus-switched scratch it rotates by
+__device__ __forceinline__ void gate_of(const GateView &gv, size_t i, size_t *gate, size_t *ms_row) {
+    const size_t f = gv.f_begin + i;
+    const size_t g = f / gv.s_count, s = f % gv.s_count;
+    const size_t u = gv.source_of ? gv.source_of[g] : g;
+    *gate = g;
+    *ms_row = u * gv.s_count + s - gv.ks_begin;
+}
+__device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t i, uint32_t ct_words) {
+    if (gv.out_rows) return gv.out_rows + i * ct_words;
+    const size_t f = gv.f_begin + i;
+    const size_t g = f / gv.s_count, s = gv.s_begin + f % gv.s_count;
+    const size_t slot = gv.dst_slot ? gv.dst_slot[g] : g;
     return gv.out_base + (slot * gv.T + s) * ct_words;
 }
 

@@ -49,7 +49,6 @@ struct ChaCha {
             out[i] = (uint64_t)(x[2 * i] + in[2 * i]) | ((uint64_t)(x[2 * i + 1] + in[2 * i + 1]) << 32);
     }
 };
-inline uint64_t fold(uint64_t r) { return r >= FQ ? r - FQ : r; }   // 2^-32 bias, documented
 }  // namespace
 
 void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count) {
@@ -222,24 +221,12 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
 }
 
 // ---------------------------------------------------------------------------------------------
-// twiddles for the merged negacyclic NTT: fwd[i] = psi^bitrev(i), inv[i] = psi^-bitrev(i).
-// psi is the primitive 2N-th root of unity with psi^(N/32) = 8, so that the twiddles of the first
-// five butterfly stages are powers of two (2 has order 192 in Z_q^*).
+// twiddles for the merged negacyclic NTT: fwd[i] = psi^bitrev(i), inv[i] = psi^-bitrev(i), psi = 7^((q-1)/2N)
+// (any primitive 2N-th root gives the same ciphertexts: the transform is an internal representation).
 // ---------------------------------------------------------------------------------------------
 void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv) {
     const uint32_t N = 1u << log_n;
-    uint64_t psi = fq_pow(7, (FQ - 1) / (2ull * N));
-    if (N >= 32) {
-        uint64_t hroot = fq_pow(psi, N / 32);   // order 64
-        uint64_t acc = hroot;
-        for (uint32_t f = 1; f < 64; f += 2) {
-            if (acc == 8) {
-                psi = fq_pow(psi, f);
-                break;
-            }
-            acc = fq_mul(acc, fq_mul(hroot, hroot));
-        }
-    }
+    const uint64_t psi = fq_pow(FQ_GENERATOR, (FQ - 1) / (2ull * N));
     const uint64_t psi_inv = fq_inv(psi);
     fwd.assign(N, 1);
     inv.assign(N, 1);

@@ -22,17 +22,25 @@ void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, si
 int64_t noise_sample(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t sigma);
 
 // ---- launch descriptors ------------------------------------------------------------------------
-// A "gate" is one Bootstrap instruction; it is applied to samples [s_begin, s_begin+s_count) of its
-// source wire.  Wire w, sample s lives at base + (w*T + s)*ct_stride words.  slot arrays may be
-// null (identity), which is the plain batch API.
+// A "gate" is one Bootstrap instruction applied to `s_count` samples of its source wire.  The bootstraps of a launch
+// are the flattened indices f in [f_begin, f_begin + count) of the [n_gates][s_count] grid: gate g = f / s_count,
+// sample s = s_begin + f % s_count.  Wire slot w, sample s lives at base + (w*T + s)*ct_words words.  Slot arrays may
+// be null (identity), which is the plain batch API.
 struct GateView {
     const uint64_t *in_base;
     uint64_t *out_base;
-    const uint32_t *src_slot;   // [n_gates] or null
+    const uint32_t *src_slot;   // [n_sources] or null: wire slot of key-switch source u
     const uint32_t *dst_slot;   // [n_gates] or null
     const uint32_t *table_ids;  // [n_gates] or null (table 0)
-    size_t T;                   // samples per wire in the buffers
-    size_t s_begin, s_count;    // sample range processed
+    // Gates that read the same wire share ONE key switch + modulus switch (reference fbs_mapper/map_to_fbs.py:41-45
+    // emits several tables per linear combination): source_of[g] = index of gate g's source in src_slot, null = g.
+    const uint32_t *source_of;  // [n_gates] or null
+    uint64_t *out_rows;         // non-null: bootstrap f writes row (f - f_begin) of this contiguous array instead of its slot
+    size_t T;                   // samples per wire in the buffers (stride)
+    size_t s_begin, s_count;    // sample window of the launch
+    size_t f_begin, count;      // bootstraps of this launch (flattened gate-major over the window)
+    size_t ks_begin, ks_count;  // key switches of this launch, flattened the same way over [n_sources][s_count];
+                                // row r of the modulus-switched scratch holds flattened source index ks_begin + r
     uint32_t n_gates;
 };
 
@@ -66,12 +74,20 @@ struct fbs_ctx {
     uint64_t *d_bsk_hat = nullptr;   // [n][rows][k+1][N]  NTT domain, lane-interleaved, x N^-1
     uint64_t *d_bsk_hat_small = nullptr;   // the same in the evaluation order of the small-launch shape (fbs_ntt.hpp), or null
     uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
+    uint64_t *d_ks_corr = nullptr;   // [ksk_stride]  (B/2) * sum of all key-switching-key rows: balanced digits from unsigned fields
     uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
     uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)
     uint32_t *d_ms = nullptr;        // scratch: mod-switched small ciphertexts [capacity][n+1]
     size_t ms_capacity = 0;
-    uint32_t *d_idx = nullptr;       // scratch for index arrays of the wires API
+    uint32_t *d_idx = nullptr;       // scratch for index arrays of the host-index wires API
     size_t idx_capacity = 0;
+    uint64_t *d_wires = nullptr;     // wire slots of fbs_eval, shared by every program of the context
+    size_t wires_capacity = 0;       // in words
+    // The scratch buffers above are shared by every call on the context.  Calls on ONE stream are ordered by the
+    // stream; a call on another stream first waits for the last user of the scratch (scratch_wait / scratch_done).
+    hipStream_t scratch_stream = nullptr;
+    hipEvent_t scratch_event = nullptr;
+    bool scratch_used = false;
 
     fbs::Profile prof;
 };
@@ -106,9 +122,16 @@ int dev_supported(const fbs_ctx *ctx);   // FBS_OK or error if no kernel instanc
 int dev_upload_keys(fbs_ctx *ctx);       // BSK -> NTT domain, KSK padded
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream);
 int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream);
-int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *d_dst,
-                const uint32_t *d_term_off, const uint32_t *d_srcs, const uint64_t *d_coefs,
+// `T` = sample stride of the wire buffer, samples [s_begin, s_begin + s_count) are computed
+int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, uint32_t n_out,
+                const uint32_t *d_dst, const uint32_t *d_term_off, const uint32_t *d_srcs, const uint64_t *d_coefs,
                 const uint64_t *d_consts, hipStream_t stream);
+// rows[f - f_begin] -> wire slot dst_slot[f / s_count], sample s_begin + f % s_count, for f in [f_begin, f_begin + count)
+int dev_scatter_rows(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, const uint32_t *d_dst_slot,
+                     const uint64_t *d_rows, size_t f_begin, size_t count, hipStream_t stream);
+// rows of `count` ciphertexts: out[i] = wires[slot][s_begin + i] (slot >= 0) or the trivial ciphertext of `body`
+int dev_copy_out(fbs_ctx *ctx, const uint64_t *d_wires, size_t T, size_t s_begin, size_t count, int64_t slot, uint64_t body,
+                 uint64_t *d_out, hipStream_t stream);
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream);
 
 // profiling helpers

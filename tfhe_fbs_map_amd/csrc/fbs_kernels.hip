@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "fbs_gate.hpp"
 #include "fbs_internal.hpp"
@@ -18,22 +19,33 @@ namespace fbs {
 // ---------------------------------------------------------------------------------------------
 // key switch + modulus switch
 //
-// out = (0, b) - sum_j sum_v digit_v(a_j) * KSK[j][v]; unsigned base-2^gamma digits of the closest multiple of
-// q/2^(t*gamma) (top t*gamma bits of the 46-bit word, rounded).  Key words are < 2^46 and there are kN*t digits
+// out = (0, b) - sum_j sum_v digit_v(a_j) * KSK[j][v]; BALANCED base-2^gamma digits (in [-B/2, B/2), carries
+// propagated) of the closest multiple of q/2^(t*gamma) (top t*gamma bits of the 46-bit word, rounded).  The kernels
+// never see a signed digit: adding B/2 at every digit position before cutting the word into bit fields gives
+// u_v = digit_v + B/2 in [0, B), and sum_v digit_v K_v = sum_v u_v K_v - (B/2) sum_v K_v, whose second term summed over
+// all j is one constant vector per key (`corr`, built at key upload).  Balanced digits carry about a quarter of the
+// key-noise variance of unsigned ones at no cost in the loop.  Key words are < 2^46 and there are kN*t fields
 // < 2^gamma per output, so a plain 64-bit accumulator holds the whole sum (checked in dev_supported) and is
 // folded mod q once at the end; the result is switched to [0, 2N) on the spot.
 // ---------------------------------------------------------------------------------------------
 struct KsArgs {
     GateView gv;
     const uint64_t *ksk;   // [D*t][stride]
+    const uint64_t *corr;  // [stride]  (B/2) * sum of all key rows, mod q
     uint32_t *ms;          // [count][n+1]
+    uint32_t offs;         // B/2 at every digit position
     uint32_t n, D, t, gamma, stride, ct_words, log2_2n;
-    size_t count;          // n_gates * s_count
+    uint32_t cols_major;   // 1: blockIdx.x walks the column blocks (see dev_keyswitch), 0: the ciphertext tiles
+    size_t row0;           // first key switch of this launch (launches are split when a grid dimension would overflow)
+    size_t count;          // key switches in all (gv.ks_count)
 };
 
-__device__ __forceinline__ uint32_t ks_round(uint64_t w, uint32_t tg) { return (uint32_t)(((w >> (FQ_BITS - 1 - tg)) + 1) >> 1); }
-__device__ __forceinline__ uint32_t ks_finish(uint64_t acc, uint64_t body, uint32_t log2_2n) {
-    const uint64_t r = fq_sub(body, acc % FQ);
+// rounded top t*gamma bits plus the digit offsets; bits above t*gamma (the rounding carry: a multiple of q) are never looked at
+__device__ __forceinline__ uint32_t ks_round(uint64_t w, uint32_t tg, uint32_t offs) {
+    return (uint32_t)(((w >> (FQ_BITS - 1 - tg)) + 1) >> 1) + offs;
+}
+__device__ __forceinline__ uint32_t ks_finish(uint64_t acc, uint64_t body, uint64_t corr, uint32_t log2_2n) {
+    const uint64_t r = fq_add(fq_sub(body, acc % FQ), corr);
     return (uint32_t)(((r >> (FQ_BITS - log2_2n - 1)) + 1) >> 1) & ((1u << log2_2n) - 1u);
 }
 
@@ -44,14 +56,14 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     extern __shared__ uint32_t abar[];   // [FB][D]
     __shared__ const uint64_t *ct_ptr[FB];
     const size_t f0 = (size_t)blockIdx.x * FB;
-    if (threadIdx.x < FB) ct_ptr[threadIdx.x] = f0 + threadIdx.x < a.count ? gate_in(a.gv, f0 + threadIdx.x, a.ct_words) : nullptr;
+    if (threadIdx.x < FB) ct_ptr[threadIdx.x] = f0 + threadIdx.x < a.count ? ks_in(a.gv, f0 + threadIdx.x, a.ct_words) : nullptr;
     __syncthreads();
     const uint32_t col = blockIdx.y * 256u + threadIdx.x;
     const uint32_t tg = a.t * a.gamma;
 
     for (uint32_t idx = threadIdx.x; idx < FB * a.D; idx += 256) {
         const uint32_t f = idx / a.D, j = idx % a.D;
-        abar[idx] = ct_ptr[f] ? ks_round(ct_ptr[f][j], tg) : 0u;
+        abar[idx] = ct_ptr[f] ? ks_round(ct_ptr[f][j], tg, a.offs) : 0u;
     }
     __syncthreads();
 
@@ -77,7 +89,7 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     for (int f = 0; f < FB; f++) {
         if (f0 + f >= a.count) break;
         const uint64_t body = col == a.n ? ct_ptr[f][a.D] : 0;
-        a.ms[(f0 + f) * (a.n + 1) + col] = ks_finish(acc[f], body, a.log2_2n);
+        a.ms[(f0 + f) * (a.n + 1) + col] = ks_finish(acc[f], body, a.corr[col], a.log2_2n);
     }
 }
 
@@ -100,8 +112,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
     static_assert(WAVES >= 2 && (WAVES & (WAVES - 1)) == 0, "tree reduction over the waves");
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const size_t f0 = (size_t)blockIdx.x * CTS;
-    const uint32_t col0 = blockIdx.y * COLS;
+    const size_t f0 = a.row0 + (size_t)(a.cols_major ? blockIdx.y : blockIdx.x) * CTS;
+    const uint32_t col0 = (a.cols_major ? blockIdx.x : blockIdx.y) * COLS;
+    if (col0 > a.n) return;                      // padding column block (the grid is padded to a multiple of the 8 XCDs)
     const uint32_t tg = a.t * a.gamma;
     const uint32_t dmask = (1u << a.gamma) - 1u;
     const uint32_t slice_len = (a.D + WAVES - 1) / WAVES;    // mask words per wave
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
             acc_lo[u][c] = 0;
             acc_hi[u][c] = 0;
         }
-    for (uint32_t q = threadIdx.x; q < CTS; q += THREADS) ct_ptr[q] = f0 + q < a.count ? gate_in(a.gv, f0 + q, a.ct_words) : nullptr;
+    for (uint32_t q = threadIdx.x; q < CTS; q += THREADS) ct_ptr[q] = f0 + q < a.count ? ks_in(a.gv, f0 + q, a.ct_words) : nullptr;
 
     for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
         __syncthreads();
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
             const uint32_t j = sl * slice_len + r0 + jj;
             uint32_t v = 0;
             const uint64_t *row = ct_ptr[q];
-            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg);
+            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg, a.offs);
             tile[(sl * JT + jj) * CTS + q] = v;
         }
         __syncthreads();
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
         for (int c = 0; c < COLS; c++) {
             const uint32_t col = col0 + c;
             if (col > a.n) break;
-            a.ms[f * (a.n + 1) + col] = ks_finish(sum[u][c], col == a.n ? body : 0, a.log2_2n);
+            a.ms[f * (a.n + 1) + col] = ks_finish(sum[u][c], col == a.n ? body : 0, a.corr[col], a.log2_2n);
         }
     }
 }
@@ -205,11 +218,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
 // ---------------------------------------------------------------------------------------------
 // linear combination over wire slots: out = sum coef_i * wire_i + const (exact FP64 products, lazy sum)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lincomb(uint64_t *wires, size_t T, uint32_t ct_words, const uint32_t *dst,
-                                                 const uint32_t *term_off, const uint32_t *srcs, const double *coefs,
-                                                 const uint64_t *consts) {
-    const uint32_t g = blockIdx.y;
-    const size_t s = blockIdx.x;
+__global__ __launch_bounds__(256) void k_lincomb(uint64_t *wires, size_t T, size_t s_begin, size_t s_count, uint32_t ct_words,
+                                                 const uint32_t *dst, const uint32_t *term_off, const uint32_t *srcs,
+                                                 const double *coefs, const uint64_t *consts) {
+    const size_t b = blockIdx.x;                 // flattened (output, sample): grid.x reaches 2^31, grid.y only 65535
+    const uint32_t g = (uint32_t)(b / s_count);
+    const size_t s = s_begin + b % s_count;
     const uint32_t t0 = term_off[g], t1 = term_off[g + 1];
     uint64_t *out = wires + ((size_t)dst[g] * T + s) * ct_words;
     for (uint32_t j = threadIdx.x; j < ct_words; j += 256) {
@@ -221,6 +235,23 @@ __global__ __launch_bounds__(256) void k_lincomb(uint64_t *wires, size_t T, uint
         }
         out[j] = fp_to_u64(fp_canon(accv));
     }
+}
+
+// rows of a contiguous array -> wire slots (the gate-sharded multi-GPU mode publishes a level's bootstraps as one
+// contiguous all-gathered array; this puts them where the next level's linear combinations look for them)
+__global__ __launch_bounds__(256) void k_scatter_rows(uint64_t *wires, size_t T, size_t s_begin, size_t s_count, uint32_t ct_words,
+                                                      const uint32_t *dst_slot, const uint64_t *rows, size_t f_begin) {
+    const size_t f = f_begin + blockIdx.x;
+    const size_t g = f / s_count, s = s_begin + f % s_count;
+    uint64_t *out = wires + ((size_t)dst_slot[g] * T + s) * ct_words;
+    const uint64_t *in = rows + (size_t)blockIdx.x * ct_words;
+    for (uint32_t j = threadIdx.x; j < ct_words; j += 256) out[j] = in[j];
+}
+
+// trivial ciphertexts (0, ..., 0, body): constant outputs of a program
+__global__ __launch_bounds__(256) void k_fill_trivial(uint64_t *out, uint32_t ct_words, uint64_t body) {
+    uint64_t *row = out + (size_t)blockIdx.x * ct_words;
+    for (uint32_t j = threadIdx.x; j < ct_words; j += 256) row[j] = j == ct_words - 1 ? body : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,7 +301,9 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     KsArgs a{};
     a.gv = gv;
     a.ksk = ctx->d_ksk;
+    a.corr = ctx->d_ks_corr;
     a.ms = d_ms;
+    for (uint32_t v = 0; v < p.t_ksk; v++) a.offs |= (1u << (p.gamma_ksk - 1)) << (v * p.gamma_ksk);
     a.n = p.n;
     a.D = ctx->D;
     a.t = p.t_ksk;
@@ -278,7 +311,7 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     a.stride = ctx->ksk_stride;
     a.ct_words = ctx->D + 1;
     a.log2_2n = p.log_n_poly + 1;
-    a.count = (size_t)gv.n_gates * gv.s_count;
+    a.count = gv.ks_count;
     if (a.count == 0) return FBS_OK;
     hipEvent_t e0, e1;
     prof_begin(ctx, 0, stream, &e0, &e1);
@@ -287,11 +320,26 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         constexpr int COLS = 8;
         // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65,
         // 256 x 8 waves 1.32, 128 x 16 waves 0.86, 256 x 16 waves 1.80
+        // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the column blocks on grid.x, padded to a
+        // multiple of 8, XCD x only ever sees the column blocks = x (mod 8): each key word is fetched by ONE XCD's L2
+        // instead of all eight (the 50 MB key does not fit any L2), and what every XCD re-reads is the 8 times
+        // smaller ciphertext batch.
+        static const bool cols_major = !(getenv("FBS_KS_TILES_MAJOR") && getenv("FBS_KS_TILES_MAJOR")[0] == '1');
+        a.cols_major = cols_major ? 1u : 0u;
         const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
-        if (a.count > 64)
-            hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 2, 8>), dim3((unsigned)((a.count + 127) / 128), cols), dim3(512), 0, stream, a);
-        else
-            hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 1, 4>), dim3(1, cols), dim3(256), 0, stream, a);
+        const unsigned cols_padded = cols_major ? (cols + 7u) / 8u * 8u : cols;
+        if (a.count > 64) {
+            const size_t tiles = (a.count + 127) / 128;
+            const size_t per_launch = cols_major ? 65535 : 0x7FFFFFFF;     // tiles sit on grid.y in the column-major form
+            for (size_t t0 = 0; t0 < tiles; t0 += per_launch) {
+                const unsigned nt = (unsigned)std::min(per_launch, tiles - t0);
+                a.row0 = t0 * 128;
+                hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 2, 8>), cols_major ? dim3(cols_padded, nt) : dim3(nt, cols), dim3(512), 0,
+                                   stream, a);
+            }
+        } else {
+            hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 1, 4>), cols_major ? dim3(cols_padded, 1) : dim3(1, cols), dim3(256), 0, stream, a);
+        }
     } else {
         constexpr int FB = 8;
         dim3 grid((unsigned)((a.count + FB - 1) / FB), ctx->ksk_stride / 256);
@@ -303,17 +351,42 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     return FBS_OK;
 }
 
-int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *d_dst,
+int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, uint32_t n_out, const uint32_t *d_dst,
                 const uint32_t *d_term_off, const uint32_t *d_srcs, const uint64_t *d_coefs, const uint64_t *d_consts,
                 hipStream_t stream) {
-    if (n_out == 0 || T == 0) return FBS_OK;
-    if (n_out > 65535) return set_error(ctx, FBS_E_INVALID, "more than 65535 linear combinations in one launch");
+    if (n_out == 0 || s_count == 0) return FBS_OK;
+    const size_t blocks = (size_t)n_out * s_count;
+    if (blocks > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "more than 2^31 linear combinations in one launch");
     hipEvent_t e0, e1;
     prof_begin(ctx, 2, stream, &e0, &e1);
     // d_coefs carries the coefficients as centred doubles (bit pattern in a uint64 array, see fbs_capi.cpp)
-    hipLaunchKernelGGL(k_lincomb, dim3((unsigned)T, n_out), dim3(256), 0, stream, d_wires, T, ctx->D + 1, d_dst, d_term_off,
-                       d_srcs, reinterpret_cast<const double *>(d_coefs), d_consts);
+    hipLaunchKernelGGL(k_lincomb, dim3((unsigned)blocks), dim3(256), 0, stream, d_wires, T, s_begin, s_count, ctx->D + 1, d_dst,
+                       d_term_off, d_srcs, reinterpret_cast<const double *>(d_coefs), d_consts);
     prof_end(ctx, 2, stream, e0, e1);
+    FBS_HIP(ctx, hipGetLastError());
+    return FBS_OK;
+}
+
+int dev_scatter_rows(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, const uint32_t *d_dst_slot,
+                     const uint64_t *d_rows, size_t f_begin, size_t count, hipStream_t stream) {
+    if (count == 0) return FBS_OK;
+    if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "more than 2^31 rows in one launch");
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)count), dim3(256), 0, stream, d_wires, T, s_begin, s_count, ctx->D + 1, d_dst_slot,
+                       d_rows, f_begin);
+    FBS_HIP(ctx, hipGetLastError());
+    return FBS_OK;
+}
+
+int dev_copy_out(fbs_ctx *ctx, const uint64_t *d_wires, size_t T, size_t s_begin, size_t count, int64_t slot, uint64_t body,
+                 uint64_t *d_out, hipStream_t stream) {
+    if (count == 0) return FBS_OK;
+    const size_t ctw = ctx->D + 1;
+    if (slot >= 0) {
+        FBS_HIP(ctx, hipMemcpyAsync(d_out, d_wires + ((size_t)slot * T + s_begin) * ctw, count * ctw * 8, hipMemcpyDeviceToDevice, stream));
+        return FBS_OK;
+    }
+    if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "more than 2^31 rows in one launch");
+    hipLaunchKernelGGL(k_fill_trivial, dim3((unsigned)count), dim3(256), 0, stream, d_out, (uint32_t)ctw, body);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;
 }

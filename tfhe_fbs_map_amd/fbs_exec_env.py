@@ -21,9 +21,11 @@ The north-star name `FbsExecEnv` is an alias of `LutExecEnv`.
 from __future__ import annotations
 
 import logging
+import os
 import re
 import sys
 import textwrap
+from collections import OrderedDict
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -62,31 +64,70 @@ def min_fbs_size(tables, at_least=2):
 @dataclass
 class ExecConfig:
     """How `LutExecEnv.eval` reaches the GPU.  `fbs_size=None` picks the smallest p that can
-    evaluate every table of the program; `params=None` picks the default set for that p."""
+    evaluate every table of the program.  `params=None` asks `params.choose_params` for the cheapest
+    parameter set that is 128-bit secure (noise from `params.sigma_min`) and leaves `min_margin`
+    standard deviations of room at the program's own (p, norm2_linprod) -- the role of the patched
+    optimizer in the reference's flow (experiments/add_exec_estimates.py:9-16).  Pass `params`
+    explicitly (e.g. `params.P1024`, the reduced-noise benchmark set) to override."""
     fbs_size: int | None = None
     params: object | None = None          # tfhe_fbs_map_amd.Params (p_msg is overridden by fbs_size)
-    seed: int = 1
+    seed: int | None = None               # key seed; None = drawn from os.urandom once per ExecConfig
     device: int = 0
-    nonce0: int = 0
-    # params=None and auto_params: the cheapest gadget / key-switch shape whose modelled margin at the program's
-    # (p, norm2_linprod) is at least min_margin sigmas (params.choose_params) instead of the fixed default set --
-    # the role of the patched optimizer in the reference's flow (experiments/add_exec_estimates.py:9-16)
-    auto_params: bool = False
-    min_margin: float = 6.0
+    nonce0: int | None = None             # first encryption nonce; None = a counter that advances with every eval()
+    min_margin: float = 6.0               # p_error ~ 2e-9 per bootstrap (the reference's optimizer default is 4 sigma)
+    security: int = 128
+    reduced_noise: bool = False           # params=None: the reduced-noise benchmark set for p (params.params_for) -- NOT secure
+    max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
+    _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)
+    _next_nonce: int = field(default=0, repr=False)
+
+    def key_seed(self):
+        if self.seed is None:
+            self.seed = int.from_bytes(os.urandom(8), "little")
+        return self.seed
 
     def context_for(self, p, norm2=1):
         from . import _native as nat
-        from .params import choose_params, params_for
-        if self.params is None and self.auto_params:
-            prm = choose_params(p, norm2, self.min_margin)
+        from .params import REFERENCE_MARGIN, choose_params, params_for
+        if self.params is None and self.reduced_noise:
+            prm = params_for(p)
+        elif self.params is None:
+            prm = choose_params(p, norm2, min_margin=self.min_margin, security=self.security,
+                                floor_margin=min(self.min_margin, REFERENCE_MARGIN))
         else:
-            prm = (self.params or params_for(p)).replace(p_msg=p)
-        key = (prm, self.seed, self.device)
+            prm = self.params.replace(p_msg=p)
+        key = (prm, self.key_seed(), self.device)
         ctx = self._contexts.get(key)
         if ctx is None:
-            ctx = self._contexts[key] = nat.Context(prm, seed=self.seed, device=self.device)
+            ctx = self._contexts[key] = nat.Context(prm, seed=self.key_seed(), device=self.device)
         return ctx
+
+    def program_for(self, ctx, low):
+        """The loaded (device-resident) form of a lowered program, cached; the cache is bounded because every entry
+        pins index tables in HBM (the wire buffer itself belongs to the context and is shared)."""
+        from . import _native as nat
+        key = (id(ctx), id(low))
+        hit = self._programs.get(key)
+        if hit is not None and hit[1] is low:
+            self._programs.move_to_end(key)
+            return hit[0]
+        tv = ctx.tvset(low["tables"])
+        prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
+                           low["term_coef"], low["term_src"], low["out_wire"])
+        self._programs[key] = (prog, low)
+        while len(self._programs) > max(1, self.max_programs):
+            _, (old, _) = self._programs.popitem(last=False)
+            old.close()
+        return prog
+
+    def take_nonces(self, count):
+        """Every ciphertext ever encrypted under one ExecConfig gets its own randomness stream."""
+        if self.nonce0 is not None:
+            return self.nonce0
+        first = self._next_nonce
+        self._next_nonce += count
+        return first
 
 
 class LutExecEnv:
@@ -351,7 +392,7 @@ class LutExecEnv:
         p = cfg.fbs_size or min_fbs_size(low["tables"])
         for t in low["tables"]:
             assert table_is_valid(t, p), "table %s cannot be evaluated by one bootstrap at fbs_size %d" % (t, p)
-        ctx = cfg.context_for(p, self.stats()["norm2_linprod"] if cfg.auto_params else 1)
+        ctx = cfg.context_for(p, self.stats()["norm2_linprod"])
 
         names = low["input_names"]
         cols = [np.asarray(input_values[n]).reshape(-1) for n in names]
@@ -359,17 +400,8 @@ class LutExecEnv:
         bits = np.stack([np.broadcast_to(c, (T,)) for c in cols]).astype(np.int64) if cols else np.zeros((0, T), np.int64)
         assert bits.size == 0 or (bits.min() >= 0 and bits.max() <= 1), "inputs are bits"
 
-        cache = getattr(ctx, "_programs", None)
-        if cache is None:
-            cache = ctx._programs = {}
-        prog = cache.get(id(low))
-        if prog is None:
-            tv = ctx.tvset(low["tables"])
-            prog = cache[id(low)] = (nat.Program(ctx, tv, len(names), low["kind"], low["arg0"], low["arg1"],
-                                                 low["const_coef"], low["term_coef"], low["term_src"],
-                                                 low["out_wire"]), low)
-        program = prog[0]
-        cts = ctx.encrypt(bits, nonce0=cfg.nonce0)
+        program = cfg.program_for(ctx, low)
+        cts = ctx.encrypt(bits, nonce0=cfg.take_nonces(bits.size))
         out = ctx.decrypt(program.eval(cts, T))
         result = {}
         for k, name in enumerate(low["out_names"]):

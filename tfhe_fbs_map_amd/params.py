@@ -1,96 +1,196 @@
-"""Parameter sets and a small noise model.
+"""Parameter sets, the security floor on the noise, a noise model and the parameter selector.
 
-The reference never fixes cryptographic parameters: it hands (precision p, squared 2-norm of the
-linear combinations) -- `stats()["norm2_linprod"]`, fbs_mapper/fbs_exec_env.py:245-276 -- to a patched
-concrete-optimizer (experiments/add_exec_estimates.py:9-16, experiments/concrete.patch:21-27) that is
-not available here.  This module is the stand-in: the BASELINE.md set P1024 and its N=2048 sibling,
-plus textbook CGGI variance formulas so a caller can see how many standard deviations of margin a
-(parameter set, p, norm2) combination has.  All variances are relative to q^2 (torus units).
+The reference never fixes cryptographic parameters: it hands (precision p = number of plaintext values, squared
+2-norm of the linear combinations) -- `stats()["norm2_linprod"]`, fbs_mapper/fbs_exec_env.py:245-276 -- to a patched
+concrete-optimizer (experiments/add_exec_estimates.py:9-16) that returns `k, N, n, br_l, br_b, ks_l, ks_b, cost`
+(experiments/concrete.patch:163) at a fixed security level and error probability (`--security-level`, default 128;
+`--p-error`, default "4 sigma", concrete.patch:56,139-140), under the contract that the noise entering a bootstrap
+stays inside half a box, q/(4p), at that probability (concrete.patch:21-27: 2^(log q - 2) / precision).  That
+optimizer is Rust, un-vendored and unbuildable here.  `choose_params` is its stand-in for THIS executor: same inputs,
+same outputs, the same contract, this executor's own noise formulas and cost unit.
 
-The default noise (sigma = 2^6 on the 46-bit modulus, i.e. 2^-40 relative) is REDUCED NOISE: it makes
-N=1024 correct for p=15 with generous margin but is far below what 128-bit security needs at these
-dimensions (~2^-25 at N=1024, which would not leave room for p=15).  Throughput does not depend on it.
+All variances are relative to q^2 (torus units).
+
+Security.  `sigma_min(dim)` is the smallest noise standard deviation for which an LWE instance of dimension `dim`
+with a binary secret is estimated to resist 2^128 operations.  It restates the 128-bit line of the security curves
+that concrete-optimizer itself uses (concrete-security-curves, generated with the lattice estimator; the optimizer's
+`minimal_variance_lwe` evaluates log2(sigma/q) = slope * dim + bias and floors it at 2^2/q):
+        slope = -0.0265994623, bias = 2.9815431841   (security level 128, binary keys)
+[NOT IN REFERENCE: restated from the public source of zama-ai/concrete at the release the reference pins
+(README.md:17); neither that source nor the estimator is available offline, so the two constants are unverifiable
+here.  Cross-check against published TFHE-rs 128-bit parameter sets: n = 742 -> 2^-16.8 here against 2^-17.1
+published; N = 2048 -> 2^-51.5 against 2^-51.6: this line is the more conservative of the two.]
+The line does not depend on q; the floor does: with the 46-bit modulus of this executor no noise is ever below
+2^-44 q, which is why N = 2048 keys are noisier here than under a 64-bit modulus (and still far inside the budget).
+
+`P1024` -- BASELINE.md's synthetic benchmark shape n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2 -- is kept for the
+throughput benchmark with REDUCED NOISE (sigma = 2^-40 q): at 128-bit noise an N = 1024 accumulator cannot carry
+p = 15 (see `margin_sigmas`), so that set is a kernel benchmark shape, not a secure configuration, and says so
+(`Params.security_bits`).
 """
 from __future__ import annotations
 
 import math
 
-from ._native import MODULUS, Params
+from ._native import Params
+from .security import MODULUS, MODULUS_BITS
 
-P1024 = Params()                                            # n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2
-# p = 31 needs the wider accumulator, and its linear combinations (norm2 up to ~325) need a finer decomposition than
-# P1024's 21 bits: 24 bits.  At the (reduced) key noise of the defaults a wide base costs nothing, so the 24 bits are
-# 3 levels of 8 rather than 4 of 6 (one forward transform less per component and step; same margin in the model
-# below, 6.3 sigma at norm2 = 325).
-P2048 = Params(n=630, log_n_poly=11, l_bsk=3, beta_bsk=8)
+# ---- security floor (constants and sigma_min live in security.py, which has no dependencies) --------------------
+from .security import MIN_LOG2_SIGMA_ABS, SECURITY_CURVES, log2_sigma_min, sigma_min      # noqa: E402,F401
+
+
+def security_bits(prm: Params) -> float:
+    """Rough security estimate of a parameter set: 128 (or more) when both noises sit on or above the 128-bit
+    line, otherwise 128 scaled by dimension over the dimension that noise would need (security is close to
+    linear in the dimension at fixed log(q/sigma))."""
+    slope, bias = SECURITY_CURVES[128]
+    worst = float("inf")
+    for dim, sigma in ((prm.n, prm.sigma_lwe), (prm.k * prm.N, prm.sigma_glwe)):
+        rel = math.log2(max(sigma, 1) / MODULUS)
+        need = (rel - bias) / slope                       # dimension at which this sigma is 128-bit secure
+        worst = min(worst, 128.0 * dim / max(need, 1.0))
+    return worst
+
+
+def with_secure_noise(prm: Params, security: int = 128) -> Params:
+    return prm.replace(sigma_lwe=sigma_min(prm.n, security), sigma_glwe=sigma_min(prm.k * prm.N, security))
+
+
+REDUCED_SIGMA = 1 << 6                                                    # 2^-40 q
+
+# BASELINE.md's benchmark shape, REDUCED NOISE (not secure; see the module docstring)
+P1024 = Params(n=630, log_n_poly=10, l_bsk=3, beta_bsk=7, t_ksk=8, gamma_ksk=2).reduced_noise(REDUCED_SIGMA)
+# its N = 2048 sibling for p = 31 (24 gadget bits as three levels of eight), REDUCED NOISE as well
+P2048 = P1024.replace(log_n_poly=11, l_bsk=3, beta_bsk=8)
+
 
 def params_for(p: int, norm2: int | None = None) -> Params:
-    """Default set for plaintext modulus p: the modulus switch alone (n = 630) leaves about
-    N / (10.2 p) standard deviations between a value and the edge of its box, so p <= 16 fits
-    N = 1024 (>= 6 sigma) and p <= 32 wants N = 2048."""
+    """The reduced-noise benchmark set for plaintext modulus p: the modulus switch alone (n = 630) leaves about
+    N / (10.2 p) standard deviations between a value and the edge of its box, so p <= 16 fits N = 1024 and p <= 32
+    wants N = 2048.  For a secure set use `choose_params`."""
     base = P1024 if p <= 16 else P2048
     return base.replace(p_msg=p)
 
 
+# ---- noise model -------------------------------------------------------------------------------------------------
 def variances(prm: Params):
     """(blind-rotate output, key switch, modulus switch) variances in torus units."""
     q = float(MODULUS)
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
     B, b2 = 2.0 ** prm.beta_bsk, 2.0 ** prm.gamma_ksk
     s_glwe, s_lwe = prm.sigma_glwe / q, prm.sigma_lwe / q
-    # external product: (k+1) l N digits of variance (B^2+2)/12 against key noise in every step, plus the
+    # external product: (k+1) l N balanced digits of variance (B^2+2)/12 against key noise in every step, plus the
     # rounding of the decomposition (half an ulp of q/B^l) seen through a binary GLWE key -- the latter only in the
     # steps whose LWE key bit is 1 (the CMUX output is s_i times the rounded difference): half of them.
     # Measured on the GPU this lands 15-35 % above the observed noise (tests/test_gpu_parity.py).
     v_br = n * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + 0.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
-    # key switch: unsigned digits in [0, 2^gamma): E[d^2] = (2^g - 1)(2^(g+1) - 1)/6
-    ed2 = (b2 - 1) * (2 * b2 - 1) / 6.0
-    v_ks = k * N * (t * ed2 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
+    # key switch: kN t balanced digits in [-2^g/2, 2^g/2) against key noise, plus the rounding to t*gamma bits
+    # seen through a binary key
+    v_ks = k * N * (t * (b2 * b2 + 2) / 12.0 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
     v_ms = (1 + n / 2.0) / (12.0 * (2.0 * N) ** 2)
     return v_br, v_ks, v_ms
 
 
 def margin_sigmas(prm: Params, norm2: float = 1.0) -> float:
-    """Half box width q/(4p) divided by the standard deviation of the phase that enters the
-    blind rotation, when the inputs of the linear combination are bootstrap outputs."""
+    """Half box width q/(4p) divided by the standard deviation of the phase that enters the blind rotation, when
+    the inputs of the linear combination are bootstrap outputs (the reference's contract, concrete.patch:21-27:
+    norm2 * bootstrap noise + key switch + modulus switch against 2^(log q - 2)/p)."""
     v_br, v_ks, v_ms = variances(prm)
     sigma = math.sqrt(norm2 * v_br + v_ks + v_ms)
     return (1.0 / (4.0 * prm.p_msg)) / sigma
 
 
+def p_error(margin: float) -> float:
+    """Probability that a Gaussian leaves +-margin standard deviations (one bootstrap)."""
+    return math.erfc(margin / math.sqrt(2.0))
+
+
 def bootstrap_cost(prm: Params) -> float:
-    """Relative cost of one functional bootstrap, in the unit the kernels are bound by: n CMUX steps of (k+1)(l+1)
-    transforms of N log N butterflies plus (k+1)^2 l N exact products, and the kN t (n+1) multiply-adds of the key
-    switch weighted by their measured share (5 % of the P1024 step).  The reference ranks parameter sets by the
-    optimizer's `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
+    """Relative cost of one functional bootstrap, in the unit the kernels are bound by (FP64 instruction issue), with
+    the default P1024 shape = 1: n CMUX steps of (k+1)(l+1) transforms of N log N / 2 butterflies (8 instructions each)
+    plus (k+1)^2 l N exact products (7 each, accumulate included), and the kN t (n+1) multiply-adds of the key switch
+    weighted by their measured share (5 % of the P1024 step).  The reference ranks parameter sets by the optimizer's
+    `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
-    blind = n * ((k + 1) * (l + 1) * N * prm.log_n_poly / 2.0 * 1.14 + (k + 1) ** 2 * l * N)
-    switch = k * N * t * (n + 1)
-    p1024_blind = 630 * (2 * 4 * 1024 * 5 * 1.14 + 4 * 3 * 1024)
-    p1024_switch = 1024 * 8 * 631
-    return 0.95 * blind / p1024_blind + 0.05 * switch / p1024_switch
+
+    def blind(n_, l_, N_, log_n):
+        return n_ * ((k + 1) * (l_ + 1) * N_ * log_n / 2.0 * 8.0 + (k + 1) ** 2 * l_ * N_ * 7.0)
+
+    return 0.95 * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.05 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
-def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, sigma: int | None = None) -> Params:
-    """Cheapest gadget / key-switch shape whose modelled margin at (p, norm2) is at least `min_margin` standard
-    deviations -- what the reference obtains from its patched optimizer for (precision, squared 2-norm)
-    (experiments/add_exec_estimates.py:9-16, experiments/concrete.patch:21-27,66-74).  n and the noise are those of
-    the default sets (`sigma` overrides both standard deviations); N is the smallest power of two whose modulus switch
-    leaves room for p.  Falls back to the shape with the largest margin when none reaches `min_margin`."""
-    base = params_for(p)
-    if sigma is not None:
-        base = base.replace(sigma_lwe=sigma, sigma_glwe=sigma)
-    # conventional shapes only: 2..6 levels of 4..12 bits, key-switch digits of 1..4 bits (the executor itself takes
-    # wider ones; with the reduced default noise the model would happily pick a single 19-bit level)
-    gadgets = [(l, beta) for l in (2, 3, 4, 5, 6) for beta in range(4, 13) if 12 <= l * beta <= 30]
-    switches = [(t, g) for t, g in ((4, 4), (5, 3), (6, 3), (8, 2), (10, 2), (16, 1), (20, 1))
-                if 46 + g + math.log2(t * base.N) <= 63.9]
-    best, best_key = None, None
-    for l, beta in gadgets:
-        for t, g in switches:
-            cand = base.replace(l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=g)
-            m = margin_sigmas(cand, norm2)
-            key = (0, bootstrap_cost(cand), -m) if m >= min_margin else (1, -m, bootstrap_cost(cand))
-            if best_key is None or key < best_key:
-                best, best_key = cand, key
-    return best
+# ---- selector ------------------------------------------------------------------------------------------------------
+REFERENCE_MARGIN = 4.0          # the optimizer's default p_error is "4 sigma" (concrete.patch:56: default_value_t = _4_SIGMA)
+
+_GADGETS = [(l, beta) for l in (1, 2, 3, 4, 5, 6) for beta in range(3, 24) if 10 <= l * beta <= 30]
+_SWITCHES = [(t, g) for g in (1, 2, 3, 4, 5, 6) for t in range(1, 24) if 8 <= t * g <= 30]
+
+
+def _switch_fits(t, g, N):
+    bits = MODULUS_BITS + g + math.log2(t * N)
+    return bits <= 63.9 and bits - 32.0 <= 31.9          # the key-switch kernels' 64-bit accumulators (dev_supported)
+
+
+def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security: int | None = 128,
+                  sigma: int | None = None, poly_sizes=(9, 10, 11), n_range=(450, 1200, 4),
+                  floor_margin: float | None = None) -> Params:
+    """Cheapest parameter set (n, N, l, beta, t, gamma and both noises) for plaintext modulus p and squared 2-norm
+    `norm2` whose modelled margin is at least `min_margin` standard deviations -- what the reference obtains from its
+    patched optimizer for (precision, sq_norm2) (experiments/add_exec_estimates.py:9-16, concrete.patch:21-27,163).
+
+    security = 128: each noise is the smallest the security line allows for its dimension (`sigma_min`); n runs over
+    `n_range`, N over 2^poly_sizes (k = 1: the kernels' shape), the gadget over 1..6 levels of 3..23 bits, the key
+    switch over 1..23 levels of 1..6 bits.  security = None with `sigma`: the same search at a fixed noise (the
+    reduced-noise benchmark setting).  Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
+    (p too large for N <= 2048 at this security level); with `floor_margin` the requirement is first relaxed in steps of
+    half a sigma down to that floor (p = 31 at norm2 = 325 tops out just under 6 sigma: the modulus switch at
+    N = 2048 alone leaves 5.9)."""
+    import numpy as np
+    if floor_margin is not None and floor_margin < min_margin:
+        m = min_margin
+        while True:
+            try:
+                return choose_params(p, norm2, m, security, sigma, poly_sizes, n_range)
+            except ValueError:
+                if m <= floor_margin:
+                    raise
+                m = max(floor_margin, m - 0.5)
+    q = float(MODULUS)
+    k = 1
+    ns = np.arange(*n_range, dtype=np.float64)
+    if security is not None:
+        s_lwe = np.array([sigma_min(int(n), security) for n in ns]) / q
+    else:
+        s_lwe = np.full(ns.shape, float(sigma if sigma is not None else REDUCED_SIGMA) / q)
+    need = (1.0 / (4.0 * p) / min_margin) ** 2              # largest admissible variance
+    best = None
+    for log_n in poly_sizes:
+        N = 1 << log_n
+        s_glwe = (sigma_min(k * N, security) if security is not None else (sigma if sigma is not None else REDUCED_SIGMA)) / q
+        v_ms = (1 + ns / 2.0) / (12.0 * (2.0 * N) ** 2)
+        if (v_ms >= need).all():
+            continue
+        for l, beta in _GADGETS:
+            B = 2.0 ** beta
+            v_br = ns * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + 0.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
+            room = need - v_ms - norm2 * v_br
+            if (room <= 0).all():
+                continue
+            for t, g in _SWITCHES:
+                if not _switch_fits(t, g, N):
+                    continue
+                b2 = 2.0 ** g
+                v_ks = k * N * (t * (b2 * b2 + 2) / 12.0 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
+                ok = np.nonzero(v_ks <= room)[0]
+                if ok.size == 0:
+                    continue
+                n = int(ns[ok[0]])                          # cost grows with n: the smallest feasible n is the cheapest
+                cand = Params(n=n, log_n_poly=log_n, k=k, l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=g, p_msg=p,
+                              sigma_lwe=int(round(s_lwe[ok[0]] * q)), sigma_glwe=int(round(s_glwe * q)))
+                key = (bootstrap_cost(cand), n, l, t)
+                if best is None or key < best[0]:
+                    best = (key, cand)
+    if best is None:
+        raise ValueError("no parameter set with N <= %d reaches %.1f sigma at p = %d, norm2 = %g"
+                         % (1 << max(poly_sizes), min_margin, p, norm2))
+    return best[1]
