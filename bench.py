@@ -1,59 +1,177 @@
 #!/usr/bin/env python3
 """Headline benchmark: functional bootstraps per second (batched), N=1024 -- BASELINE.json configs[1].
 
-A "step" is one pass of the hot path (key switch + modulus switch + blind rotation + sample extraction)
-over one synthetic batch of `--batch` independent ciphertexts per GPU, inputs and outputs resident in
-HBM.  N > 1: one process per GPU (torch.distributed.run), the batch is per rank (weak scaling), keys are
-replicated, no data-path collective; time is max over ranks between barriers.
+    python bench.py [--gpus N] [--steps K] [--warmup W]                      # the headline (workload "batch")
+    python bench.py --workload circuit --mode gate|sample [--gpus N] ...     # BASELINE configs[3] stand-in
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel: blind rotation,
-timed live with HIP events on its own stream through libfbsexec's profile hooks) and `cpu_baseline`
-(the CPU oracle on a bounded sample of the same batch, all host cores; N=1 only).
+A "step" is one pass of the hot path (key switch + modulus switch + blind rotation + sample extraction)
+  batch:   over one synthetic batch of `--batch` independent ciphertexts per GPU (weak scaling: keys replicated,
+           no data-path collective);
+  circuit: over one whole mapped program (default: the reference's trivium_stream_v2 mapped @15 by its search
+           mapper, tests/golden fixture) on `--samples` samples, level by level --
+           mode gate:   every level's (gate, sample) batch cut across the ranks, one RCCL all-gather per level
+                        (north_star's shape; strong scaling: the program and T are fixed);
+           mode sample: every rank evaluates the whole program on its own `--samples` samples (weak scaling).
+Inputs and outputs are resident in HBM.  Time is the max over ranks between barrier + synchronize on both sides.
+
+--gpus N with no WORLD_SIZE in the environment: this process only LAUNCHES -- it starts N ranks with
+`python -m torch.distributed.run` as a child process before anything here touches the GPU, relays rank 0's JSON line
+and exits with the child's code.  With WORLD_SIZE set (the driver's own torchrun) it is a rank.
+
+Prints ONE JSON line (rank 0): the contract fields, `roofline` for the dominant kernel (blind rotation, timed live with
+HIP events on its own stream through libfbsexec's profile hooks), and at N=1 `cpu_baseline` (the CPU oracle on a
+bounded sample of the same batch) and `secure` (the same batch at the 128-bit-secure parameter set for p = 15).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8.0 TB/s spec
+CLOCK_HZ = 2.4e9           # nominal engine clock
+SIMDS = 256 * 4            # 256 CUs x 4 SIMDs, one FP64 VALU wave-instruction per SIMD per 4 cycles
+PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_blind_rotate.json")   # counters of the timed kernel, collected offline
 
-HBM_PEAK = 8.0e12      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="independent FBS per GPU per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["batch", "circuit"], default="batch")
+    ap.add_argument("--batch", type=int, default=1024, help="batch: independent FBS per GPU per step")
+    ap.add_argument("--mode", choices=["gate", "sample"], default="gate", help="circuit: what is cut across the ranks")
+    ap.add_argument("--circuit", default="trivium_stream_v2__search_p15", help="circuit: fixture under tests/golden")
+    ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
-    args = ap.parse_args()
+    ap.add_argument("--no-secure", action="store_true", help="skip the secure-parameter-set leg")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 20 if args.workload == "batch" else 2
+    if args.warmup is None:
+        args.warmup = 3 if args.workload == "batch" else 1
+    return args
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def launch(args, argv):
+    """Parent of an N-rank run: never touches the GPU (no torch.cuda call, no HIP call)."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout.splitlines():
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+    if child.returncode != 0 or line is None:
+        sys.stderr.write(child.stderr[-4000:])
+        errs = [o for o in child.stdout.splitlines() if o.startswith("{") and '"error"' in o]
+        sys.stderr.write("\n".join(errs[-args.gpus:]) + "\nbench.py: the %d-rank run failed (exit code %d)\n" % (args.gpus, child.returncode))
+        return child.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def worker(args):
+    import numpy as np
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    have_gpu = torch.cuda.is_available()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if have_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")         # a GPU-less host: the ranks still meet, then fail at the context
+    elif have_gpu:
+        torch.cuda.set_device(local)
 
-    from tfhe_fbs_map_amd import Context, Params
-    prm = Params()                                   # P1024, p = 15
-    ctx = Context(prm, seed=1, device=local)         # keys replicated: every rank derives them from the seed
-    B = args.batch
+    from tfhe_fbs_map_amd import FbsError
+    try:
+        result = run_batch(args, rank, world, local, dist) if args.workload == "batch" else run_circuit(args, rank, world, local, dist)
+    except FbsError as e:
+        # no CPU path: a rank without a usable gfx950 device says so and fails
+        print(json.dumps(dict(error=str(e), code=e.code, rank=rank, name="FBS_E_DEVICE" if e.code == -2 else "FBS_E_%d" % -e.code)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 3
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def fence(dist):
+    import torch
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(value, dist):
+    import torch
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_ok(ok, dist):
+    import torch
+    if dist is None:
+        return ok
+    flag = torch.tensor([1 if ok else 0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def params_record(prm):
+    """What the numbers were taken at: shape, both noises and the security they amount to."""
+    import math
+    from tfhe_fbs_map_amd import MODULUS
+    from tfhe_fbs_map_amd.params import margin_sigmas, security_bits
+    return dict(n=prm.n, N=prm.N, k=prm.k, l=prm.l_bsk, beta=prm.beta_bsk, t=prm.t_ksk, gamma=prm.gamma_ksk, p=prm.p_msg,
+                sigma_lwe=prm.sigma_lwe, sigma_glwe=prm.sigma_glwe,
+                log2_sigma_lwe_over_q=round(math.log2(prm.sigma_lwe / MODULUS), 2),
+                log2_sigma_glwe_over_q=round(math.log2(prm.sigma_glwe / MODULUS), 2),
+                security_bits_estimate=round(security_bits(prm), 1),
+                margin_sigmas_at_norm2_1=round(margin_sigmas(prm, 1), 2))
+
+
+def timed_batch(ctx, prm, B, rank, steps, warmup, dist, n_tables=16):
+    """`steps` passes over one resident batch of B ciphertexts; returns (seconds, profile, tables, cts, ids, msgs, out, ok)."""
+    import numpy as np
+    import torch
+    p = prm.p_msg
     rng = np.random.default_rng(42)
-    tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(n_tables)]
     tv = ctx.tvset(tables)
     rng = np.random.default_rng(42 + rank)
-    msgs = rng.integers(0, 15, B)
-    ids = (np.arange(B) % 16).astype(np.uint32)
+    msgs = rng.integers(0, p, B)
+    ids = (np.arange(B) % n_tables).astype(np.uint32)
     cts = ctx.encrypt(msgs, nonce0=rank * B)
     d_in = torch.from_numpy(cts.view(np.int64)).cuda()
     d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
@@ -63,80 +181,121 @@ def main():
     def step():
         ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, d_out.data_ptr(), stream)
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     ctx.profile(True)
     ctx.profile_read(reset=True)
-    fence()
+    fence(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    fence()
+    fence(dist)
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read(reset=True)
     ctx.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
     out = d_out.cpu().numpy().view(np.uint64)
     ok = bool(np.array_equal(ctx.decrypt(out), [tables[i][m] for i, m in zip(ids, msgs)]))
-    if dist is not None:
-        flag = torch.tensor([1 if ok else 0], device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = bool(flag.item())
+    return elapsed, prof, tables, cts, ids, msgs, out, ok
 
-    if rank == 0:
-        value = world * B * args.steps / elapsed
-        br_ms = prof["blind_rotate"]["ms"] / max(1, prof["blind_rotate"]["launches"])
-        ks_ms = prof["keyswitch"]["ms"] / max(1, prof["keyswitch"]["launches"])
-        N, n, k = prm.N, prm.n, prm.k
-        # algorithmic bytes of ONE blind-rotation launch: per FBS every bootstrapping-key row once, the test
-        # vector, the mod-switched input and the extracted output (DESIGN.md "Bytes"); SURVEY 8(d)'s whole-FBS
-        # figure (103 309 328 B) additionally holds the key-switching key, which is the other kernel's.
-        br_bytes_per_fbs = n * (k + 1) * prm.l_bsk * (k + 1) * N * 8 + N * 8 + (n + 1) * 4 + (k * N + 1) * 8
-        achieved = br_bytes_per_fbs * B / (br_ms * 1e-3)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_blind_rotate.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="hbm", kernel="k_blind_rotate<10,6,true,1>", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=achieved / HBM_PEAK, traffic=traffic, avg_launch_ms=br_ms, bytes_per_unit=br_bytes_per_fbs,
-                        units_per_launch=B, keyswitch_avg_launch_ms=ks_ms,
-                        whole_path_bytes_per_fbs=prm.bytes_per_fbs(),
-                        whole_path_frac=value / world * prm.bytes_per_fbs() / HBM_PEAK,
-                        note="achieved/frac are ALGORITHMIC bytes over time; the key stream is served from L2/MALL after first "
-                             "touch (traffic = PMC-measured fabric bytes per launch) and the kernel is bound by FP64 issue: "
-                             "4.8e9 VALU wave-instructions per launch (PMC) against a measured ceiling of one v_fma_f64 per SIMD per "
-                             "4.8-5.0 nominal cycles at two waves per SIMD (profiles/r01/fp64_issue_rate.txt) = 9.7 ms; see DESIGN.md")
-        result = dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world,
-                      steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                      higher_is_better=True, scaling="weak", vs_baseline=None,
-                      dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)",
-                      data="synthetic",
-                      config=dict(workload="BASELINE configs[1]: %d independent FBS per GPU per step, P1024 "
-                                           "(n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2), p=15, 16 random tables" % B,
-                                  batch_per_gpu=B, parallelism="replicas of the batch per GPU, keys replicated, no collective",
-                                  device=ctx.device_info),
-                      decrypt_ok=ok, roofline=roofline)
-        if world == 1 and args.cpu_sample != 0:
-            result["cpu_baseline"] = cpu_baseline(prm, tables, cts, ids, out, args.cpu_sample)
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def roofline_record(prm, prof, B):
+    """The dominant kernel is the blind rotation.  It is bound by FP64 VALU issue, not by HBM: every workgroup walks the
+    bootstrapping key in step, so after the first touch the key comes out of L2 / Infinity Cache (PMC: a few % of the
+    algorithmic bytes reach the fabric).  `frac` is therefore the fraction of the chip's FP64 issue slots the kernel
+    fills: VALU wave-instructions per launch (PMC SQ_INSTS_VALU, collected offline with rocprofv3 on this very
+    command, profiles/r02/) x 4 cycles / (1024 SIMDs x 2.4 GHz) / the average launch time measured live here."""
+    br, ks = prof["blind_rotate"], prof["keyswitch"]
+    br_ms = br["ms"] / max(1, br["launches"])
+    ks_ms = ks["ms"] / max(1, ks["launches"])
+    N, n, k = prm.N, prm.n, prm.k
+    # algorithmic bytes of ONE blind-rotation launch: per FBS every bootstrapping-key row once, the test vector, the
+    # mod-switched input and the extracted output; SURVEY 8(d)'s whole-FBS figure (103 309 328 B at P1024)
+    # additionally holds the key-switching key, which is the other kernel's
+    br_bytes_per_fbs = n * (k + 1) * prm.l_bsk * (k + 1) * N * 8 + N * 8 + (n + 1) * 4 + (k * N + 1) * 8
+    rec = dict(bound="fp64_valu", kernel=br["kernel"], unit="VALU wave-instr/s", avg_launch_ms=br_ms, units_per_launch=B,
+               peak=SIMDS * CLOCK_HZ / 4.0, achieved=None, frac=None, valu_frac=None, traffic=None,
+               hbm_algorithmic_frac=br_bytes_per_fbs * B / (br_ms * 1e-3) / HBM_PEAK,
+               hbm_algorithmic_bytes_per_fbs=br_bytes_per_fbs, hbm_algorithmic_GBps=br_bytes_per_fbs * B / (br_ms * 1e-3) / 1e9,
+               keyswitch_kernel=ks["kernel"], keyswitch_avg_launch_ms=ks_ms,
+               note="bound by FP64 VALU issue (one wave-instruction per SIMD per 4 cycles at the nominal 2.4 GHz); "
+                    "hbm_algorithmic_* count every key row once per bootstrap as SURVEY 8(d) prescribes, but the key is served "
+                    "from L2/Infinity Cache after first touch: `traffic` is what reached the fabric")
+    if os.path.exists(PMC_FILE):
+        pmc = json.load(open(PMC_FILE)).get(br["kernel"])
+        if pmc and pmc.get("units_per_launch") == B and pmc.get("n") == n:
+            insts = pmc["SQ_INSTS_VALU_per_launch"]
+            rec["achieved"] = insts / (br_ms * 1e-3)
+            rec["valu_frac"] = rec["frac"] = rec["achieved"] / rec["peak"]
+            rec["valu_insts_per_launch"] = insts
+            rec["valu_insts_per_wave_per_step"] = pmc.get("valu_per_wave_per_step")
+            rec["traffic"] = dict(bytes_per_launch=pmc.get("hbm_bytes_per_launch"), source=pmc.get("source"),
+                                  collected="offline, separate rocprofv3 --pmc passes of this command")
+    return rec
+
+
+def run_batch(args, rank, world, local, dist):
+    import numpy as np
+    from tfhe_fbs_map_amd import P1024, Context
+    prm = P1024                                       # reduced-noise benchmark set, p = 15
+    ctx = Context(prm, seed=1, device=local)          # keys replicated: every rank derives them from the seed
+    B = args.batch
+    elapsed, prof, tables, cts, ids, msgs, out, ok = timed_batch(ctx, prm, B, rank, args.steps, args.warmup, dist)
+    elapsed = max_over_ranks(elapsed, dist)
+    ok = all_ok(ok, dist)
+    if rank != 0:
+        return None
+    value = world * B * args.steps / elapsed
+    result = dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world,
+                  steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+                  higher_is_better=True, scaling="weak", vs_baseline=None,
+                  dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)",
+                  data="synthetic",
+                  config=dict(workload="BASELINE configs[1]: %d independent FBS per GPU per step, P1024 "
+                                       "(n=630 N=1024 k=1 l=3 beta=7 t=8 gamma=2), p=15, 16 random tables; REDUCED NOISE "
+                                       "(a kernel benchmark shape, not a secure configuration: see `params` and `secure`)" % B,
+                              batch_per_gpu=B, parallelism="replicas of the batch per GPU, keys replicated, no collective",
+                              device=ctx.device_info, params=params_record(prm)),
+                  decrypt_ok=ok, roofline=roofline_record(prm, prof, B))
+    if world == 1 and args.cpu_sample != 0:
+        result["cpu_baseline"] = cpu_baseline(prm, tables, cts, ids, out, args.cpu_sample)
+    ctx.close()
+    if world == 1 and not args.no_secure:
+        result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
+    return result
+
+
+def secure_leg(B, local, steps):
+    """The same batch at the parameter set `choose_params` returns for p = 15 at norm2 = 70 (the 16x16 multiplier's and
+    the adder's linear combinations), 128-bit noise, 6 sigma: what a deployment would run."""
+    from tfhe_fbs_map_amd import Context, choose_params
+    from tfhe_fbs_map_amd.params import bootstrap_cost, margin_sigmas
+    prm = choose_params(15, 70)
+    ctx = Context(prm, seed=1, device=local)
+    elapsed, prof, *_, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
+    br, ks = prof["blind_rotate"], prof["keyswitch"]
+    rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok, params=params_record(prm),
+               margin_sigmas_at_norm2_70=round(margin_sigmas(prm, 70), 2), modelled_cost_vs_p1024=round(bootstrap_cost(prm), 3),
+               blind_rotate_kernel=br["kernel"], blind_rotate_avg_launch_ms=br["ms"] / max(1, br["launches"]),
+               keyswitch_avg_launch_ms=ks["ms"] / max(1, ks["launches"]))
+    ctx.close()
+    return rec
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(prm, tables, cts, ids, gpu_out, sample):
-    """The oracle (a plain-C port, OpenMP over independent FBS) on the first `sample` ciphertexts of the
-    same batch, same keys; also checks those ciphertexts bit-for-bit against the GPU's."""
+    """The oracle (a plain-C port, OpenMP over independent FBS) on the first `sample` ciphertexts of the same batch,
+    same keys, on all the cores this process may use -- and on ONE thread; also checks those
+    ciphertexts bit-for-bit against the GPU's."""
+    import numpy as np
     from oracle import tfhe_oracle
     cores = os.cpu_count() or 1
     try:
@@ -151,10 +310,114 @@ def cpu_baseline(prm, tables, cts, ids, gpu_out, sample):
     t0 = time.perf_counter()
     ref, used = orc.bootstrap_batch(cts[:sample], tables, ids[:sample], threads=cores)
     dt = time.perf_counter() - t0
-    return dict(value=sample / dt, unit="FBS/s", cores=used, kind="port",
+    one = max(1, min(sample, 24))
+    t0 = time.perf_counter()
+    orc.bootstrap_batch(cts[:one], tables, ids[:one], threads=1)
+    dt1 = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="FBS/s", cores=used, kind="port", cpu_model=cpu_model(),
                 sample="first %d ciphertexts of the timed batch, %.1f s" % (sample, dt),
+                one_thread=dict(value=one / dt1, unit="FBS/s", sample="first %d ciphertexts, %.1f s" % (one, dt1)),
                 bit_exact_vs_gpu=bool(np.array_equal(ref, gpu_out[:sample])))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+def run_circuit(args, rank, world, local, dist):
+    import gzip
+    import numpy as np
+    import torch
+    from tfhe_fbs_map_amd import Context, Program, min_fbs_size, params_for, parse_fbs
+    from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend
+
+    with gzip.open(os.path.join(ROOT, "tests", "golden", args.circuit + ".json.gz"), "rb") as f:
+        rec = json.loads(f.read().decode())
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+    low = env.lower()
+    stats = env.stats()
+    tail = args.circuit.rsplit("_p", 1)[-1].split("_")[0]            # fixtures are named <circuit>__<mapper>_p<fbs_size>
+    p = int(tail) if tail.isdigit() else min_fbs_size(low["tables"])
+    prm = params_for(p)                                               # the reduced-noise benchmark set for p
+    ctx = Context(prm, seed=1, device=local)
+    prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                   low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    T = args.samples
+    # gate mode: every rank holds the SAME T samples; sample mode: rank r its own T samples
+    rng = np.random.default_rng(42 + (rank if args.mode == "sample" else 0))
+    bits = rng.integers(0, 2, (prog.n_inputs, T))
+    clear = cleartext(low, bits)
+    d_in = torch.from_numpy(ctx.encrypt(bits, nonce0=0).view(np.int64)).cuda()
+    collectives = lambda: 0                                                          # noqa: E731
+    if args.mode == "gate":
+        runner = GateShardedRunner(GpuBackend(prog))
+        step = lambda: runner.run_device(d_in, T)                                   # noqa: E731
+        collectives = lambda: runner.collectives                                    # noqa: E731
+    else:
+        # sample-sharded: the rank's share IS the whole program on its own samples -- one device-side call, no exchange
+        d_out = torch.empty((prog.n_outputs, T, prm.ct_words), dtype=torch.int64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def step():
+            prog.eval_dev(d_in.data_ptr(), T, d_out.data_ptr(), stream)
+            return d_out
+    for _ in range(args.warmup):
+        out = step()
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    fence(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence(dist)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist)
+    prof = ctx.profile_read(reset=True)
+    got = ctx.decrypt(out.cpu().numpy().view(np.uint64))
+    ok = all(np.array_equal(got[k], clear[k]) for k, w in enumerate(low["out_wire"]) if w >= 0)
+    ok = all_ok(ok, dist)
+    if rank != 0:
+        return None
+    fbs_per_eval = prog.n_bootstrap * T * (world if args.mode == "sample" else 1)
+    value = fbs_per_eval * args.steps / elapsed
+    return dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world, steps=args.steps,
+                warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+                scaling="strong" if args.mode == "gate" else "weak", vs_baseline=None,
+                dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)", data="synthetic",
+                config=dict(workload="BASELINE configs[3] stand-in: %s (reference mapper output, %d bootstraps, depth %d, widest level %d) "
+                                     "on %d samples%s, reduced-noise benchmark set" % (args.circuit, prog.n_bootstrap, prog.depth, prog.max_width, T,
+                                                                              " per rank" if args.mode == "sample" else ""),
+                            mode=args.mode, rccl_ranks=world, collectives_per_step=collectives() // max(1, args.steps + args.warmup),
+                            parallelism=("levels cut across ranks, one all-gather per level" if args.mode == "gate" else
+                                         "samples cut across ranks, no data-path collective"),
+                            wire_slots=prog.n_slots, wires=prog.n_inputs + len(low["kind"]), key_switches=prog.n_keyswitch,
+                            norm2_linprod=stats["norm2_linprod"], device=ctx.device_info, params=params_record(prm)),
+                decrypt_ok=ok,
+                kernels_ms_per_step={k: v["ms"] / args.steps for k, v in prof.items()})
+
+
+def cleartext(low, bits):
+    """What the program computes in the clear (the reference's LutExecEnv.eval loop, fbs_exec_env.py:208-229, on the
+    lowered arrays) -- the check of the bench's own outputs, not a timed path."""
+    import numpy as np
+    n_in = len(low["input_names"])
+    wires = [bits[i].astype(np.int64) for i in range(n_in)]
+    for i, kind in enumerate(low["kind"]):
+        if kind == 0:
+            a, c = low["arg0"][i], low["arg1"][i]
+            v = np.full(bits.shape[1], low["const_coef"][i], np.int64)
+            for t in range(a, a + c):
+                v = v + low["term_coef"][t] * wires[low["term_src"][t]]
+            wires.append(v)
+        else:
+            table = np.asarray(low["tables"][low["arg1"][i]], np.int64)
+            wires.append(table[wires[low["arg0"][i]]])
+    return [wires[w] if w >= 0 else np.full(bits.shape[1], -1 - w, np.int64) for w in low["out_wire"]]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args, argv)
+    return worker(args)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

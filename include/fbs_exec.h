@@ -42,6 +42,7 @@ extern "C" {
 #define FBS_E_DEVICE (-2)    /* HIP error (no GPU, OOM, launch failure ...)       */
 #define FBS_E_STATE (-3)     /* call out of order (e.g. eval before keygen)       */
 #define FBS_E_TABLE (-4)     /* table violates the negacyclic contract for p      */
+#define FBS_E_POLY_SIZE (-5) /* polynomial size rejected (see fbs_poly_size_check) */
 
 typedef struct fbs_params {
     uint32_t n;          /* small LWE dimension (P1024: 630)                      */
@@ -55,6 +56,17 @@ typedef struct fbs_params {
     uint64_t sigma_lwe;  /* std-dev of key-switch-key noise, in units of 1/q       */
     uint64_t sigma_glwe; /* std-dev of bootstrap-key and fresh-input noise, same  */
 } fbs_params;
+
+/* Polynomial sizes.  fbs_params carries log2 N: the ring is Z_q[X]/(X^N + 1) with N a power of two (this build:
+ * 256 .. 2048).  BASELINE config 5 also names "non-power-of-two N".  That is rejected on purpose, not for lack of a
+ * transform (2N | q - 1 holds for N = 3 * 2^k under this modulus): for N = m * 2^k with m odd > 1, X^N + 1 is not
+ * cyclotomic -- y^m + 1 is divisible by y + 1, so X^N + 1 has the factor X^(2^k) + 1 and every GLWE sample maps onto
+ * the power-of-two ring of degree N/m, whose (smaller) dimension then bounds the security: N = 1536 is no safer than
+ * N = 512 and costs three times as much.  The reference's patch generalises the plaintext modulus p, not N
+ * (experiments/concrete.patch:85-90); odd p at power-of-two N is what this library runs for that config.
+ * Returns FBS_OK, FBS_E_POLY_SIZE for a non-power-of-two (text via fbs_last_error(NULL)), FBS_E_INVALID for a power
+ * of two outside the supported range. */
+int fbs_poly_size_check(uint32_t poly_size);
 
 typedef struct fbs_ctx fbs_ctx;
 typedef struct fbs_tvset fbs_tvset;
@@ -198,6 +210,9 @@ int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
  * launches[i] = number of launches. */
 int fbs_profile_enable(fbs_ctx *ctx, int on);
 int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset);
+/* name of the kernel instantiation the most recent launch of kind `which` (0, 1, 2 as above) used: the launcher
+ * picks the shape by parameter set and batch size */
+const char *fbs_profile_kernel(const fbs_ctx *ctx, int which);
 /* block until all work queued on the context's stream (or `stream`) has finished */
 int fbs_sync(fbs_ctx *ctx, void *stream);
 

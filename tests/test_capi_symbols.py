@@ -53,6 +53,19 @@ def test_bad_parameters_rejected_before_touching_the_device():
         assert e.value.code == -1
 
 
+def test_non_power_of_two_polynomial_size_is_refused_with_its_own_code():
+    """BASELINE config 5 names a non-power-of-two N; DESIGN.md says why that ring is refused."""
+    from tfhe_fbs_map_amd import FbsError, Params
+    for n_poly in (1536, 768, 3 * 1024, 1000):
+        with pytest.raises(FbsError) as e:
+            Params.for_poly_size(n_poly)
+        assert e.value.code == -5 and "not a power of two" in str(e.value)
+    with pytest.raises(FbsError) as e:
+        Params.for_poly_size(4096)
+    assert e.value.code == -1
+    assert Params.for_poly_size(2048, p_msg=31).log_n_poly == 11
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "tfhe_fbs_map_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -37,7 +37,7 @@ def load(nat, toy_params, name, T, seed=6, merge=True):
     return rec, ctx, prm, low, cts, prog, expect, (ops, outs)
 
 
-@pytest.mark.parametrize("name", ["adder8__basic_p2", "2_input_gates__basic_p2", "aes_sbox__basic_p2"])
+@pytest.mark.parametrize("name", ["adder8__basic_p2", "2_input_gates__basic_p2", "half_adder__basic_p2"])
 def test_gates_that_share_a_source_share_its_key_switch(nat, toy_params, name):
     """The reference's one-gate-one-bootstrap lowering puts several tables on one linear combination
     (map_to_fbs.py:41-45; its CSE only merges identical tables, fbs_exec_env.py:93-100): the loaded program runs ONE
@@ -58,9 +58,13 @@ def test_gates_that_share_a_source_share_its_key_switch(nat, toy_params, name):
             assert np.array_equal(ctx.decrypt(got[k]), expect[out_name])
 
 
-def test_search_mapped_programs_have_nothing_to_share(nat, toy_params):
-    _, _, _, _, _, prog, _, _ = load(nat, toy_params, "aes_sbox__search_p7", 1)
-    assert prog.n_keyswitch == prog.n_bootstrap
+def test_key_switch_count_is_the_number_of_distinct_sources(nat, toy_params):
+    """The heuristic mappers rarely put two tables on one linear combination: whatever they did, the
+    loaded program switches each distinct source once."""
+    for name in ("aes_sbox__search_p7", "mul4__naive_p7"):
+        _, _, _, _, _, prog, _, (ops, _) = load(nat, toy_params, name, 1)
+        boots = [op for op in ops if op[0] == "boot"]
+        assert prog.n_bootstrap == len(boots) and prog.n_keyswitch == len({op[2] for op in boots})
 
 
 @pytest.mark.parametrize("name", ["adder8__search_p7", "mul4__naive_p7", "adder8__basic_p2"])

@@ -67,6 +67,15 @@ class Params:
         if self.sigma_glwe is None:
             object.__setattr__(self, "sigma_glwe", sigma_min(self.k * (1 << self.log_n_poly)))
 
+    @classmethod
+    def for_poly_size(cls, poly_size: int, **kw):
+        """Parameter set for polynomial size N.  A non-power-of-two N (BASELINE config 5 names one) raises
+        FbsError(FBS_E_POLY_SIZE): see include/fbs_exec.h `fbs_poly_size_check` for why that ring is refused."""
+        rc = lib.fbs_poly_size_check(int(poly_size))
+        if rc != 0:
+            raise FbsError(rc, lib.fbs_last_error(None).decode())
+        return cls(log_n_poly=int(poly_size).bit_length() - 1, **kw)
+
     def reduced_noise(self, sigma: int = 1 << 6):
         """The same shape with both noises at `sigma` (default 2^6 = 2^-40 q): throughput benchmarks and parity tests
         only -- far below what any security level needs at these dimensions."""
@@ -117,6 +126,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     vp, u64, u32, sz, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_int
     sig = {
+        "fbs_poly_size_check": (i32, [u32]),
         "fbs_ctx_create": (i32, [C.POINTER(_Params), u64, i32, C.POINTER(vp)]),
         "fbs_ctx_destroy": (None, [vp]),
         "fbs_last_error": (C.c_char_p, [vp]),
@@ -145,6 +155,7 @@ def _load():
         "fbs_level_scatter_dev": (i32, [vp, vp, u32, vp, sz, sz, sz, vp, sz, sz, vp]),
         "fbs_profile_enable": (i32, [vp, i32]),
         "fbs_profile_read": (i32, [vp, C.POINTER(C.c_double * 3), C.POINTER(u64 * 3), i32]),
+        "fbs_profile_kernel": (C.c_char_p, [vp, i32]),
         "fbs_sync": (i32, [vp, vp]),
         "fbs_debug_polymul": (i32, [vp, vp, vp, vp]),
     }
@@ -156,12 +167,12 @@ def _load():
 
 
 EXPORTED_SYMBOLS = (
-    "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
+    "fbs_poly_size_check", "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
     "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_destroy", "fbs_program_info",
     "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
-    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
+    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
 )
 
 lib = _load()
@@ -340,7 +351,8 @@ class Context:
         cnt = (C.c_uint64 * 3)()
         self._check(lib.fbs_profile_read(self._h, C.byref(ms), C.byref(cnt), int(reset)))
         names = ("keyswitch", "blind_rotate", "lincomb")
-        return {n: dict(ms=ms[i], launches=int(cnt[i])) for i, n in enumerate(names)}
+        return {n: dict(ms=ms[i], launches=int(cnt[i]), kernel=lib.fbs_profile_kernel(self._h, i).decode())
+                for i, n in enumerate(names)}
 
     def sync(self, stream=0):
         self._check(lib.fbs_sync(self._h, stream or None))

@@ -373,7 +373,10 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     prof_begin(ctx, 1, stream, &e0, &e1);
     switch (p.log_n_poly) {
 #define LAUNCH_LL(L, LL_, SMALL, FPW)                                                                                  \
-    hipLaunchKernelGGL((k_blind_rotate<L, LL_, SMALL, FPW>), grid, dim3((2 << (LL_)) * FPW), 0, stream, a)
+    do {                                                                                                               \
+        ctx->prof.kernel[1] = "k_blind_rotate<" #L "," + std::to_string(LL_) + "," #SMALL "," #FPW ">";                 \
+        hipLaunchKernelGGL((k_blind_rotate<L, LL_, SMALL, FPW>), grid, dim3((2 << (LL_)) * FPW), 0, stream, a);        \
+    } while (0)
 #define LAUNCH(L, SMALL, FPW) LAUNCH_LL(L, lanes_log2_for(L), SMALL, FPW)
 #define X(L)                                                                                                           \
     case L:                                                                                                            \

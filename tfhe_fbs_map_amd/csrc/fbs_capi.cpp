@@ -117,6 +117,20 @@ static GateView batch_view(const uint64_t *in, uint64_t *out, const uint32_t *ta
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------
+int fbs_poly_size_check(uint32_t poly_size) {
+    if (poly_size == 0) return set_error(nullptr, FBS_E_INVALID, "polynomial size 0");
+    if (poly_size & (poly_size - 1)) {
+        uint32_t pow2 = poly_size & (~poly_size + 1);   // largest power of two dividing N
+        return set_error(nullptr, FBS_E_POLY_SIZE,
+                         "N = " + std::to_string(poly_size) + " is not a power of two: X^N + 1 then has the factor X^" +
+                             std::to_string(pow2) + " + 1, so a GLWE sample over it is no harder than one of degree " +
+                             std::to_string(pow2) + "; use a power-of-two N (256 .. 2048) and any plaintext modulus p");
+    }
+    if (poly_size < 256 || poly_size > 2048)
+        return set_error(nullptr, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048");
+    return FBS_OK;
+}
+
 int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) {
     if (!params || !out) return set_error(nullptr, FBS_E_INVALID, "null argument");
     *out = nullptr;
@@ -861,6 +875,11 @@ int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset
         }
     }
     return FBS_OK;
+}
+
+const char *fbs_profile_kernel(const fbs_ctx *ctx, int which) {
+    if (!ctx || which < 0 || which > 2) return "";
+    return ctx->prof.kernel[which].c_str();
 }
 
 int fbs_sync(fbs_ctx *ctx, void *stream) {

@@ -50,6 +50,7 @@ struct Profile {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double ms[3] = {0, 0, 0};
     uint64_t launches[3] = {0, 0, 0};
+    std::string kernel[3];   // instantiation of the most recent launch of each kind
 };
 
 }  // namespace fbs

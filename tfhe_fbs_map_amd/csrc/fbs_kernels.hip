@@ -113,7 +113,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const size_t f0 = a.row0 + (size_t)(a.cols_major ? blockIdx.y : blockIdx.x) * CTS;
-    const uint32_t col0 = (a.cols_major ? blockIdx.x : blockIdx.y) * COLS;
+    // column-major grid: workgroups with equal blockIdx.x mod 8 share an XCD (round-robin dispatch); give each XCD
+    // PAIRS of adjacent column blocks, so that both 64-byte halves of every 128-byte key line are used from one L2
+    const uint32_t bx = blockIdx.x;
+    const uint32_t col0 = (a.cols_major ? (((bx & 7u) << 1) | ((bx >> 3) & 1u) | ((bx >> 4) << 4)) : blockIdx.y) * COLS;
     if (col0 > a.n) return;                      // padding column block (the grid is padded to a multiple of the 8 XCDs)
     const uint32_t tg = a.t * a.gamma;
     const uint32_t dmask = (1u << a.gamma) - 1u;
@@ -321,29 +324,32 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65,
         // 256 x 8 waves 1.32, 128 x 16 waves 0.86, 256 x 16 waves 1.80
         // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the column blocks on grid.x, padded to a
-        // multiple of 8, XCD x only ever sees the column blocks = x (mod 8): each key word is fetched by ONE XCD's L2
+        // multiple of 16 and dealt in adjacent pairs, XCD x only ever sees column blocks 2x, 2x+1 (mod 16): each key line is fetched by ONE XCD's L2
         // instead of all eight (the 50 MB key does not fit any L2), and what every XCD re-reads is the 8 times
         // smaller ciphertext batch.
         static const bool cols_major = !(getenv("FBS_KS_TILES_MAJOR") && getenv("FBS_KS_TILES_MAJOR")[0] == '1');
         a.cols_major = cols_major ? 1u : 0u;
         const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
-        const unsigned cols_padded = cols_major ? (cols + 7u) / 8u * 8u : cols;
+        const unsigned cols_padded = cols_major ? (cols + 15u) / 16u * 16u : cols;
         if (a.count > 64) {
             const size_t tiles = (a.count + 127) / 128;
             const size_t per_launch = cols_major ? 65535 : 0x7FFFFFFF;     // tiles sit on grid.y in the column-major form
             for (size_t t0 = 0; t0 < tiles; t0 += per_launch) {
                 const unsigned nt = (unsigned)std::min(per_launch, tiles - t0);
                 a.row0 = t0 * 128;
+                ctx->prof.kernel[0] = "k_keyswitch_lanes<8,2,8>";
                 hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 2, 8>), cols_major ? dim3(cols_padded, nt) : dim3(nt, cols), dim3(512), 0,
                                    stream, a);
             }
         } else {
+            ctx->prof.kernel[0] = "k_keyswitch_lanes<8,1,4>";
             hipLaunchKernelGGL((k_keyswitch_lanes<COLS, 1, 4>), cols_major ? dim3(cols_padded, 1) : dim3(1, cols), dim3(256), 0, stream, a);
         }
     } else {
         constexpr int FB = 8;
         dim3 grid((unsigned)((a.count + FB - 1) / FB), ctx->ksk_stride / 256);
         size_t shmem = (size_t)FB * ctx->D * sizeof(uint32_t);
+        ctx->prof.kernel[0] = "k_keyswitch<8>";
         hipLaunchKernelGGL(k_keyswitch<FB>, grid, dim3(256), shmem, stream, a);
     }
     prof_end(ctx, 0, stream, e0, e1);
@@ -360,6 +366,7 @@ int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_
     hipEvent_t e0, e1;
     prof_begin(ctx, 2, stream, &e0, &e1);
     // d_coefs carries the coefficients as centred doubles (bit pattern in a uint64 array, see fbs_capi.cpp)
+    ctx->prof.kernel[2] = "k_lincomb";
     hipLaunchKernelGGL(k_lincomb, dim3((unsigned)blocks), dim3(256), 0, stream, d_wires, T, s_begin, s_count, ctx->D + 1, d_dst,
                        d_term_off, d_srcs, reinterpret_cast<const double *>(d_coefs), d_consts);
     prof_end(ctx, 2, stream, e0, e1);

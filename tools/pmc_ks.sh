@@ -1,15 +1,20 @@
 #!/bin/bash
+# fabric traffic of the key-switch kernel (FETCH_SIZE / WRITE_SIZE, separate passes) for the grid order in $FBS_KS_TILES_MAJOR
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/pmc_ks
-for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_ks/$(echo $c | cut -c1-12 | tr " " _) -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
+OUT=gpurun_out/pmc_ks_${1:-default}
+rm -rf $OUT && mkdir -p $OUT
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-secure > /dev/null 2> $OUT/$c.err
 done
 python3 - <<PY
-import glob, csv, collections
-for f in sorted(glob.glob("gpurun_out/pmc_ks/*/*/*counter_collection.csv")):
-    acc=collections.defaultdict(list)
+import glob, csv, collections, json
+acc=collections.defaultdict(list)
+for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "keyswitch" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in acc.items(): print("%-24s %.4g" % (k, sum(v)/len(v)))
+        if "keyswitch" in r["Kernel_Name"] or "blind_rotate" in r["Kernel_Name"]:
+            acc[("keyswitch" if "keyswitch" in r["Kernel_Name"] else "blind_rotate", r["Counter_Name"])].append(float(r["Counter_Value"]))
+out={"%s.%s_KB"%k: sum(v)/len(v) for k,v in acc.items()}
+for k in ("keyswitch","blind_rotate"):
+    out[k+".bytes_per_launch"]=(2*out.get(k+".FETCH_SIZE_KB",0)+out.get(k+".WRITE_SIZE_KB",0))*1024
+print(json.dumps(out)); json.dump(out, open("$OUT/summary.json","w"))
 PY

@@ -1,22 +1,16 @@
 #!/bin/bash
-# rocprofv3 evidence for profiles/: kernel-trace stats of bench.py, then HBM traffic counters in their own passes
+# rocprofv3 evidence for profiles/rNN: kernel-trace stats of the default bench.py run, then PMC counters in their own
+# passes (no trace domains mixed in), summarised per kernel by tools/profile_summary.py.
+#   usage (on the GPU box): bash tools/profile_round.sh [tag]      -> gpurun_out/prof_<tag>/
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 10 --cpu-sample 0 > gpurun_out/bench_kt.json 2> gpurun_out/bench_kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2>&1
-python3 - <<PY
-import glob, csv, collections, json
-out={}
-for tag in ("fetch","write"):
-    for f in glob.glob("gpurun_out/prof_%s/*/*counter_collection.csv"%tag):
-        acc=collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            k="blind_rotate" if "blind_rotate" in r["Kernel_Name"] else "keyswitch" if "keyswitch" in r["Kernel_Name"] else None
-            if k: acc[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
-        for (k,c),v in acc.items(): out["%s.%s"%(k,c)]=sum(v)/len(v)
-print(json.dumps(out))
-json.dump(out, open("gpurun_out/traffic_raw.json","w"))
-PY
-cat gpurun_out/prof_kt/*/*kernel_stats.csv | head -6
-cat gpurun_out/bench_kt.json
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT && mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 10 --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"; do
+  d=$OUT/pmc_$(echo $c | cut -c1-14 | tr " " _)
+  rocprofv3 --pmc $c --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2> $d.err
+done
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 tools/profile_summary.py $OUT > $OUT/summary.json
+cat $OUT/summary.json
