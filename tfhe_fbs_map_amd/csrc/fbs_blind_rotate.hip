@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "fbs_gate.hpp"
 #include "fbs_internal.hpp"
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__res
         double x[W::E];
 #pragma unroll
         for (int m = 0; m < W::E; m++) x[m] = fp_from_u64(src[p * W::N + W::template index_of<0>(t, m)]);
-        W::forward(x, xc, t, Twiddles(tw_fwd, tw_fwd));
+        W::forward(x, xc, t, Twiddles(tw_fwd + W::LANE_TABLE_OFFSET, tw_fwd));
 #pragma unroll
         for (int m = 0; m < W::E; m++) dst[p * W::N + W::key_word(t, m)] = fp_center(fp_mulmod(x[m], n_inv));
     }
@@ -63,25 +64,39 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
         x[m] = fp_from_u64(a[W::template index_of<0>(t, m)]);
         y[m] = fp_from_u64(b[W::template index_of<0>(t, m)]);
     }
-    W::forward(x, xc, t, Twiddles(tw_fwd, tw_fwd));
-    W::forward(y, xc, t, Twiddles(tw_fwd, tw_fwd));
+    W::forward(x, xc, t, Twiddles(tw_fwd + W::LANE_TABLE_OFFSET, tw_fwd));
+    W::forward(y, xc, t, Twiddles(tw_fwd + W::LANE_TABLE_OFFSET, tw_fwd));
 #pragma unroll
     for (int m = 0; m < W::E; m++) x[m] = fp_mulmod(fp_mulmod(x[m], fp_center(y[m])), n_inv);
-    W::inverse(x, xc, t, Twiddles(tw_inv, tw_inv));
+    W::inverse(x, xc, t, Twiddles(tw_inv + W::LANE_TABLE_OFFSET, tw_inv));
 #pragma unroll
     for (int m = 0; m < W::E; m++) c[W::template index_of<0>(t, m)] = fp_to_u64(fp_canon(x[m]));
 }
 
 // ---------------------------------------------------------------------------------------------
-// SMALL_DIGITS: beta <= 9, so a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double, AND
-// l <= 5, so the 2l lazy products (each below 0.75 q) that enter the inverse transform stay below 8 q
+// DIG: what the launcher knows about the gadget --
+//   0  nothing;
+//   1  l <= 5: the 2l lazy products (each below 0.8 q) that enter the inverse transform stay below 8 q (its first centring
+//      pass is spared);
+//   2  also beta <= 9: a balanced digit (|d| <= 2^8) times a twiddle (|w| <= 2^45) is exact in a double;
+//   3  also beta <= 7: the first butterfly stage of the forward transforms is two exact FMAs (first_butterfly, fbs_ntt.hpp)
+//   4  l = 1 (one wide digit, any beta: the shape the 128-bit parameter sets take at N = 2048): as 1, without the loop
+//      over further levels -- and without the registers the compiler keeps alive for it
 // FPW: bootstraps per workgroup.  The hardware deals the waves of a workgroup round the four SIMDs of a CU but starts
 // every workgroup at the same SIMD often enough that two-wave workgroups pile up on two SIMDs while the other two
 // idle whenever a CU holds fewer than four of them (measured: 512 bootstraps took 9.7 ms, 256 took 5.7 ms); four-wave
 // workgroups (two bootstraps) always cover all four SIMDs.
-template <int LOGN, int LL, bool SMALL_DIGITS, int FPW>
+template <int LOGN, int LL, int DIG, int FPW>
 __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = typename NttFor<LOGN, LL>::type;
+    constexpr int FIRST = DIG == 3 ? 2 : DIG == 2 ? 1 : 0;
+    constexpr bool BOUNDED = DIG >= 1;
+    constexpr bool ONE_LEVEL = DIG == 4;
+#ifndef FBS_PEEL_MAX_LL
+#define FBS_PEEL_MAX_LL 6   // measured: peeling costs the two-waves-per-polynomial shapes more in spills than it saves
+#endif
+    // first level peeled off the loop (it assigns the sums instead of adding to zeros): pays where registers allow
+    constexpr bool PEEL = ONE_LEVEL || LL <= FBS_PEEL_MAX_LL;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds_all[FPW * 2 * 2 * N];   // [bootstrap][component][ping-pong][N]
     const uint32_t sub = threadIdx.x >> (LL + 1);          // which bootstrap of the workgroup
@@ -91,14 +106,14 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     double *mine = lds + comp * 2 * N;
     double *theirs = lds + (comp ^ 1u) * 2 * N;
     typename W::Xchg xc{mine, 0};
-    Twiddles twf(a.tw_fwd, a.tw_fwd), twi(a.tw_inv, a.tw_inv);
+    Twiddles twf(a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_fwd), twi(a.tw_inv + W::LANE_TABLE_OFFSET, a.tw_inv);
     if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) {
         // One exchange buffer per polynomial (fbs_ntt.hpp); the other half of each component's region
         // holds a twiddle table instead (forward in component 0's, inverse in component 1's), so the per-lane
         // twiddle gathers are LDS reads, not 64-address global loads.
         xc.stride = 0;
         double *table = mine + N;
-        const double *src = comp ? a.tw_inv : a.tw_fwd;
+        const double *src = (comp ? a.tw_inv : a.tw_fwd) + W::LANE_TABLE_OFFSET;
 #pragma unroll
         for (int m = 0; m < E; m++) table[t + (uint32_t)LANES * m] = src[t + (uint32_t)LANES * m];
         __syncthreads();
@@ -186,9 +201,9 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 
         // ---- digits, least significant level first; NTT; multiply-accumulate with the key row ---
         double own[E], other[E];   // contributions to this component and to the partner's (lazy sums)
-#pragma unroll
-        for (int m = 0; m < E; m++) own[m] = other[m] = 0.0;
-        for (int lv = (int)a.l - 1; lv >= 0; lv--) {
+        // one gadget level; ASSIGN: the first one initialises the sums instead of adding to zeros
+        auto level = [&](int lv, auto assign) {
+            constexpr bool ASSIGN = decltype(assign)::value;
             const uint32_t shift = ((uint32_t)a.l - 1u - (uint32_t)lv) * a.beta;
             double x[E];
 #pragma unroll
@@ -202,7 +217,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             // asking for more ahead of time (all of it, or the partner's polynomial too) spills and loses again.
             constexpr int EARLY = E / 4;
             double2 ko[E / 2];
-            W::template forward<SMALL_DIGITS>(x, xc, t, twf, [&] {
+            W::template forward<FIRST>(x, xc, t, twf, [&] {
 #pragma unroll
                 for (int m = 0; m < EARLY; m++) ko[m] = k_own[m * LANES + t];
             });
@@ -213,15 +228,26 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             double2 kt[E / 2];
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
-                own[2 * j] += fp_mulmod(x[2 * j], ko[j].x);
-                own[2 * j + 1] += fp_mulmod(x[2 * j + 1], ko[j].y);
+                const double p0 = fp_mulmod(x[2 * j], ko[j].x), p1 = fp_mulmod(x[2 * j + 1], ko[j].y);
+                own[2 * j] = ASSIGN ? p0 : own[2 * j] + p0;
+                own[2 * j + 1] = ASSIGN ? p1 : own[2 * j + 1] + p1;
                 kt[j] = k_oth[j * LANES + t];
             }
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
-                other[2 * j] += fp_mulmod(x[2 * j], kt[j].x);
-                other[2 * j + 1] += fp_mulmod(x[2 * j + 1], kt[j].y);
+                const double p0 = fp_mulmod(x[2 * j], kt[j].x), p1 = fp_mulmod(x[2 * j + 1], kt[j].y);
+                other[2 * j] = ASSIGN ? p0 : other[2 * j] + p0;
+                other[2 * j + 1] = ASSIGN ? p1 : other[2 * j + 1] + p1;
             }
+        };
+        if constexpr (PEEL) {
+            level((int)a.l - 1, std::true_type{});
+            if constexpr (!ONE_LEVEL)
+                for (int lv = (int)a.l - 2; lv >= 0; lv--) level(lv, std::false_type{});
+        } else {
+#pragma unroll
+            for (int m = 0; m < E; m++) own[m] = other[m] = 0.0;
+            for (int lv = (int)a.l - 1; lv >= 0; lv--) level(lv, std::false_type{});
         }
 
         // ---- hand the partner its half of the external product (same ping-pong slot in both regions) ----
@@ -234,16 +260,16 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             // one-buffer exchanges: the partner may still be reading its buffer, which is where this hand-off lands
             if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) __syncthreads();
 #pragma unroll
-            for (int m = 0; m < E; m++) theirs[slot + m * LANES + t] = other[m];
+            for (int m = 0; m < E; m++) theirs[slot + W::handoff_word(t, m)] = other[m];
             __syncthreads();
 #pragma unroll
-            for (int m = 0; m < E; m++) own[m] += mine[slot + m * LANES + t];
+            for (int m = 0; m < E; m++) own[m] += mine[slot + W::handoff_word(t, m)];
         }
 
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
-        W::template inverse<SMALL_DIGITS>(own, xc, t, twi, inv_uni);
+        W::template inverse<BOUNDED>(own, xc, t, twi, inv_uni);
 #pragma unroll
-        for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);   // |.| <= 9 q -> centred
+        for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);   // |.| <= 17 q -> centred
     }
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
@@ -305,16 +331,16 @@ int dev_upload_keys(fbs_ctx *ctx) {
     const uint32_t N = ctx->N;
     std::vector<uint64_t> fwd, inv;
     host_twiddles(p.log_n_poly, fwd, inv);
-    std::vector<double> fwd_c(N), inv_c(N);
-    for (uint32_t i = 0; i < N; i++) {
+    std::vector<double> fwd_c(2 * (size_t)N), inv_c(2 * (size_t)N);   // the table and its two half-size subtrees (host_twiddles)
+    for (uint32_t i = 0; i < 2 * N; i++) {
         fwd_c[i] = fq_centered(fwd[i]);
         inv_c[i] = fq_centered(inv[i]);
     }
     const size_t bsk_words = (size_t)p.n * ctx->rows * (p.k + 1) * N;
     const size_t ksk_rows = (size_t)ctx->D * p.t_ksk;
     if (!ctx->d_tw_fwd) {
-        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, N * 8));
-        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, 2 * (size_t)N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, 2 * (size_t)N * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_bsk_hat, bsk_words * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ksk, ksk_rows * ctx->ksk_stride * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ks_corr, (size_t)ctx->ksk_stride * 8));
@@ -328,8 +354,8 @@ int dev_upload_keys(fbs_ctx *ctx) {
         for (uint32_t i = 0; i <= p.n; i++) corr[i] = fq_mul((uint64_t)(sum[i] % FQ), 1ull << (p.gamma_ksk - 1));
     }
     FBS_HIP(ctx, hipMemcpyAsync(ctx->d_ks_corr, corr.data(), corr.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_fwd, fwd_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
-    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_inv, inv_c.data(), N * 8, hipMemcpyHostToDevice, ctx->stream));
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_fwd, fwd_c.data(), fwd_c.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_tw_inv, inv_c.data(), inv_c.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     FBS_HIP(ctx, hipMemsetAsync(ctx->d_ksk, 0, ksk_rows * ctx->ksk_stride * 8, ctx->stream));
     FBS_HIP(ctx, hipMemcpy2DAsync(ctx->d_ksk, (size_t)ctx->ksk_stride * 8, ctx->ksk.data(), (size_t)(p.n + 1) * 8,
                                   (size_t)(p.n + 1) * 8, ksk_rows, hipMemcpyHostToDevice, ctx->stream));
@@ -366,41 +392,44 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
-    const bool small_digits = p.beta_bsk <= 9 && p.l_bsk <= 5;
+    const int dig = p.l_bsk > 5 ? 0 : p.l_bsk == 1 ? 4 : p.beta_bsk <= 7 ? 3 : p.beta_bsk <= 9 ? 2 : 1;
     // at most one bootstrap per CU: the shape with twice the waves per bootstrap, where there is one (fbs_ntt.hpp)
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
     switch (p.log_n_poly) {
-#define LAUNCH_LL(L, LL_, SMALL, FPW)                                                                                  \
+#define LAUNCH_LL(L, LL_, DIG, FPW)                                                                                    \
     do {                                                                                                               \
-        ctx->prof.kernel[1] = "k_blind_rotate<" #L "," + std::to_string(LL_) + "," #SMALL "," #FPW ">";                 \
-        hipLaunchKernelGGL((k_blind_rotate<L, LL_, SMALL, FPW>), grid, dim3((2 << (LL_)) * FPW), 0, stream, a);        \
+        ctx->prof.kernel[1] = "k_blind_rotate<" #L "," + std::to_string(LL_) + "," #DIG "," #FPW ">";                   \
+        hipLaunchKernelGGL((k_blind_rotate<L, LL_, DIG, FPW>), grid, dim3((2 << (LL_)) * FPW), 0, stream, a);          \
     } while (0)
-#define LAUNCH(L, SMALL, FPW) LAUNCH_LL(L, lanes_log2_for(L), SMALL, FPW)
+#define LAUNCH_DIG(L, LL_, FPW)                                                                                        \
+    do {                                                                                                               \
+        if (dig == 4) LAUNCH_LL(L, LL_, 4, FPW);                                                                       \
+        else if (dig == 3) LAUNCH_LL(L, LL_, 3, FPW);                                                                  \
+        else if (dig == 2) LAUNCH_LL(L, LL_, 2, FPW);                                                                  \
+        else if (dig == 1) LAUNCH_LL(L, LL_, 1, FPW);                                                                  \
+        else LAUNCH_LL(L, LL_, 0, FPW);                                                                                \
+    } while (0)
 #define X(L)                                                                                                           \
     case L:                                                                                                            \
         if constexpr (lanes_log2_for_small_launch(L) != lanes_log2_for(L)) {                                           \
             if (small_launch) {                                                                                        \
                 a.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);                                    \
-                if (small_digits) LAUNCH_LL(L, lanes_log2_for_small_launch(L), true, 1);                               \
-                else LAUNCH_LL(L, lanes_log2_for_small_launch(L), false, 1);                                           \
+                LAUNCH_DIG(L, lanes_log2_for_small_launch(L), 1);                                                      \
                 break;                                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
         if constexpr (lanes_log2_for(L) == 6) {                                                                        \
-            if (pair && small_digits) LAUNCH(L, true, 2);                                                              \
-            else if (pair) LAUNCH(L, false, 2);                                                                        \
-            else if (small_digits) LAUNCH(L, true, 1);                                                                 \
-            else LAUNCH(L, false, 1);                                                                                  \
+            if (pair) LAUNCH_DIG(L, lanes_log2_for(L), 2);                                                             \
+            else LAUNCH_DIG(L, lanes_log2_for(L), 1);                                                                  \
         } else {                                                                                                       \
-            if (small_digits) LAUNCH(L, true, 1);                                                                      \
-            else LAUNCH(L, false, 1);                                                                                  \
+            LAUNCH_DIG(L, lanes_log2_for(L), 1);                                                                       \
         }                                                                                                              \
         break;
         FBS_FOR_EACH_SHAPE(X)
 #undef X
-#undef LAUNCH
+#undef LAUNCH_DIG
 #undef LAUNCH_LL
         default: return set_error(ctx, FBS_E_INVALID, "unsupported N");
     }

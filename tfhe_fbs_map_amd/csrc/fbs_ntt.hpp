@@ -38,6 +38,27 @@ struct Twiddles {
 #define FBS_ONE_BUFFER_MAX_LL 7
 #endif
 
+// First Cooley-Tukey butterfly of a forward transform, (a, b) <- (a + w b, a - w b), by what is known about the inputs:
+//   FIRST = 0  nothing (|a|, |b| <= q): the general product, 8 instructions;
+//   FIRST = 1  |b| <= 2^8 (gadget digits, beta <= 9): b * w is exact in a double, 6 instructions;
+//   FIRST = 2  |a|, |b| <= 2^6 (beta <= 7): a +- w b is an integer below 2^51 + 2^6, EXACT in one FMA each and left
+//              UNREDUCED -- 2 instructions.  Every later butterfly reduces only the operand it multiplies, so all values of
+//              the transform then sit near 2^51 and grow by less than 0.8 q a stage: below 2^51.2 after eleven stages,
+//              inside the 2^52 that fp_mulmod (butterflies and key products alike) accepts, and every sum exact.
+template <int FIRST>
+__device__ __forceinline__ void first_butterfly(double &a, double &b, double w) {
+    if constexpr (FIRST == 2) {
+        const double u = a, d = b;
+        a = __builtin_fma(d, w, u);
+        b = __builtin_fma(-d, w, u);
+    } else {
+        const double u = a;
+        const double v = FIRST == 1 ? fp_mulmod_exact(b, w) : fp_mulmod(b, w);
+        a = u + v;
+        b = u - v;
+    }
+}
+
 template <int LOGN, int LL>
 struct PolyNtt {
     static constexpr int N = 1 << LOGN;
@@ -116,9 +137,8 @@ struct PolyNtt {
 
     // Cooley-Tukey stages of group G on registers.  The twiddles of a stage are requested before the butterflies of
     // the stage before it, so their (LDS or scalar-cache) latency hides behind arithmetic.
-    // SMALL: the inputs of the transform are below 2^8 in magnitude (gadget digits), so the products of the very first
-    // stage are exact without the FMA remainder
-    template <int G, bool SMALL>
+    // FIRST describes the inputs of the transform and with them the very first stage (see `first_butterfly`)
+    template <int G, int FIRST>
     __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
@@ -133,9 +153,13 @@ struct PolyNtt {
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
-                const double u = x[m];
                 const double wv = w[s - s_begin][m >> (bit + 1)];
-                const double v = (SMALL && s == 0) ? fp_mulmod_exact(x[m + hm], wv) : fp_mulmod(x[m + hm], wv);
+                if (s == 0) {
+                    first_butterfly<FIRST>(x[m], x[m + hm], wv);
+                    continue;
+                }
+                const double u = x[m];
+                const double v = fp_mulmod(x[m + hm], wv);
                 x[m] = u + v;
                 x[m + hm] = u - v;
             }
@@ -171,17 +195,17 @@ struct PolyNtt {
     };
     // `before_last` runs right before the butterflies of the last group: the place to issue global loads whose
     // results are wanted when the transform ends (one group of butterflies ~ one L2 round trip)
-    template <int G, bool SMALL, class Hook>
+    template <int G, int FIRST, class Hook>
     __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         if constexpr (G + 1 == GROUPS) before_last();
-        fwd_group<G, SMALL>(x, t, tw);
+        fwd_group<G, FIRST>(x, t, tw);
         if constexpr (G + 1 < GROUPS) {
             double *buf = xc.next();
             if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) sync();   // one buffer: the stores stay behind the reads that filled x
             store_group<G>(buf, t, x);
             sync();
             load_group<G + 1>(buf, t, x);
-            fwd_from<G + 1, SMALL>(x, xc, t, tw, before_last);
+            fwd_from<G + 1, FIRST>(x, xc, t, tw, before_last);
         }
     }
     template <int G>
@@ -200,12 +224,12 @@ struct PolyNtt {
     // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
     // (last-group layout, |x| < 9.3 q)
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
-        fwd_from<0, false>(x, xc, t, tw, NoHook{});
+        fwd_from<0, 0>(x, xc, t, tw, NoHook{});
     }
-    // the same for inputs below 2^8 in magnitude when SMALL is set
-    template <bool SMALL, class Hook>
+    // the same with a promise about the inputs (FIRST, see first_butterfly)
+    template <int FIRST, class Hook>
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
-        fwd_from<0, SMALL>(x, xc, t, tw, before_last);
+        fwd_from<0, FIRST>(x, xc, t, tw, before_last);
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q).  BOUNDED (a promise
     // of |x| <= 8 q) is accepted for interface parity with SplitNtt and not used: four-stage groups need the centring.
@@ -220,6 +244,10 @@ struct PolyNtt {
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inv_from<GROUPS - 1>(x, xc, t, tw);
     }
+
+    static constexpr int LANE_TABLE_OFFSET = 0;   // per-lane twiddle gathers read the uploaded table from its start
+    // word (of the partner's exchange buffer) where thread t parks register m of a polynomial handed over between components
+    __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (uint32_t)m * LANES + t; }
 
     // Key storage: the evaluation held in register m of lane t after forward() sits at word
     // ((m/2)*LANES + t)*2 + (m&1) of its polynomial, so the lanes read a polynomial with E/2 fully

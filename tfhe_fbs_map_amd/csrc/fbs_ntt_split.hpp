@@ -32,6 +32,8 @@ struct SplitNtt {
 
     __device__ static __forceinline__ void sync() { Base::sync(); }
     __host__ __device__ static constexpr uint32_t key_word(uint32_t t, int m) { return Base::key_word(t, m); }
+    static constexpr int LANE_TABLE_OFFSET = 0;
+    __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (uint32_t)m * LANES + t; }
     // input / output layout of the coefficient domain: register m of lane t = coefficient t + LANES * m
     template <int G>
     __device__ static __forceinline__ uint32_t index_of(uint32_t t, int m) {
@@ -70,8 +72,13 @@ struct SplitNtt {
     struct GroupTw {
         double w[LOGEH][EH / 2];
     };
+    // R: node of the twiddle tree this transform hangs from -- 1 for a whole polynomial, 2 + h when it is half h of a
+    // polynomial twice the size (PairNtt below); wave-uniform.  Only the scalar (wave-uniform) reads index the big tree
+    // with it: `tw.lane` always points at a table of THIS transform's own tree (node 1 = its root), so that per-lane
+    // gather addresses keep compile-time offsets -- with a run-time root every (group, stage, half) costs a VGPR for
+    // its own address, and the blind rotation has none to spare.
     template <int G, int H>
-    __device__ static __forceinline__ void load_twiddles(uint32_t t, const Twiddles &tw, GroupTw &g) {
+    __device__ static __forceinline__ void load_twiddles(uint32_t t, const Twiddles &tw, GroupTw &g, uint32_t R = 1) {
         constexpr int lo = lo_of(G);
         const uint32_t hi_part = t >> lo;
 #pragma unroll
@@ -79,12 +86,12 @@ struct SplitNtt {
             const int s = G * LOGEH + k;
             const int bit = LOGM - 1 - s - lo;
             const int sh = lo + LOGEH - LOGM + s;
-            const uint32_t root = (uint32_t)(2 + H) << s;
+            const uint32_t root = (uint32_t)(2 + H) << s, uroot = (2u * R + (uint32_t)H) << s;
 #pragma unroll
             for (int j = 0; j < EH / 2; j++) {
                 if (j >= (EH >> (bit + 1))) continue;
                 // lo >= LL: no lane bit reaches the block index -- the twiddle is wave-uniform (scalar cache, SGPRs)
-                g.w[k][j] = lo >= LL ? tw.uniform[root + (uint32_t)j] : tw.lane[root + ((hi_part << sh) | (uint32_t)j)];
+                g.w[k][j] = lo >= LL ? tw.uniform[uroot + (uint32_t)j] : tw.lane[root + ((hi_part << sh) | (uint32_t)j)];
             }
         }
     }
@@ -143,46 +150,42 @@ struct SplitNtt {
         __device__ __forceinline__ void operator()() const {}
     };
 
-    // SMALL: |x| < 2^8 on entry (gadget digits): the products of the first stage are exact in one multiply
-    template <bool SMALL, class Hook>
-    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
+    // FIRST: what is known about the inputs (first_butterfly, fbs_ntt.hpp)
+    template <int FIRST, class Hook>
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last,
+                                                   uint32_t R = 1) {
         double *half0 = xc.next(), *half1 = half0 + N / 2;
         {
-            const double w0 = tw.uniform[1];
+            const double w0 = tw.uniform[R];
 #pragma unroll
-            for (int r = 0; r < EH; r++) {
-                const double u = x[r];
-                const double v = SMALL ? fp_mulmod_exact(x[r + EH], w0) : fp_mulmod(x[r + EH], w0);
-                x[r] = u + v;
-                x[r + EH] = u - v;
-            }
+            for (int r = 0; r < EH; r++) first_butterfly<FIRST>(x[r], x[r + EH], w0);
         }
         static_assert(GROUPS == 3, "written out for three groups per half");
         GroupTw ta, tb;
-        load_twiddles<0, 0>(t, tw, ta);
-        load_twiddles<0, 1>(t, tw, tb);
+        load_twiddles<0, 0>(t, tw, ta, R);
+        load_twiddles<0, 1>(t, tw, tb, R);
         fwd_group<0, 0>(x, ta);
         exchange<0, 1, 0>(x, half0, t);
-        load_twiddles<1, 0>(t, tw, ta);
+        load_twiddles<1, 0>(t, tw, ta, R);
         pin();
         fwd_group<0, 1>(x, tb);
         exchange<0, 1, 1>(x, half1, t);
-        load_twiddles<1, 1>(t, tw, tb);
+        load_twiddles<1, 1>(t, tw, tb, R);
         pin();
         fwd_group<1, 0>(x, ta);
         exchange<1, 2, 0>(x, half0, t);
-        load_twiddles<2, 0>(t, tw, ta);
+        load_twiddles<2, 0>(t, tw, ta, R);
         pin();
         fwd_group<1, 1>(x, tb);
         exchange<1, 2, 1>(x, half1, t);
-        load_twiddles<2, 1>(t, tw, tb);
+        load_twiddles<2, 1>(t, tw, tb, R);
         pin();
         before_last();
         fwd_group<2, 0>(x, ta);
         fwd_group<2, 1>(x, tb);
     }
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
-        forward<false>(x, xc, t, tw, NoHook{});
+        forward<0>(x, xc, t, tw, NoHook{});
     }
     // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q, which spares the first centring pass) -> N * coefficients (|x| <= 8 q)
     // The wave-uniform twiddles of the inverse (last group of each half + the joining stage).  Scalar loads share the
@@ -192,11 +195,11 @@ struct SplitNtt {
         GroupTw a, b;
         double w0;
     };
-    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t t, const Twiddles &tw) {
+    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t t, const Twiddles &tw, uint32_t R = 1) {
         InvUniform u;
-        load_twiddles<0, 0>(t, tw, u.a);
-        load_twiddles<0, 1>(t, tw, u.b);
-        u.w0 = tw.uniform[1];
+        load_twiddles<0, 0>(t, tw, u.a, R);
+        load_twiddles<0, 1>(t, tw, u.b, R);
+        u.w0 = tw.uniform[R];
         return u;
     }
     template <bool BOUNDED = false>
@@ -204,20 +207,21 @@ struct SplitNtt {
         inverse<BOUNDED>(x, xc, t, tw, inverse_uniform(t, tw));
     }
     template <bool BOUNDED = false>
-    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &uni) {
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &uni,
+                                                   uint32_t R = 1) {
         double *half0 = xc.next(), *half1 = half0 + N / 2;
         GroupTw ta, tb;
-        load_twiddles<2, 0>(t, tw, ta);
-        load_twiddles<2, 1>(t, tw, tb);
+        load_twiddles<2, 0>(t, tw, ta, R);
+        load_twiddles<2, 1>(t, tw, tb, R);
         const GroupTw &t0a = uni.a, &t0b = uni.b;
         const double w0 = uni.w0;
         inv_group<2, 0, !BOUNDED>(x, ta);
         exchange<2, 1, 0>(x, half0, t);
-        load_twiddles<1, 0>(t, tw, ta);
+        load_twiddles<1, 0>(t, tw, ta, R);
         pin();
         inv_group<2, 1, !BOUNDED>(x, tb);
         exchange<2, 1, 1>(x, half1, t);
-        load_twiddles<1, 1>(t, tw, tb);
+        load_twiddles<1, 1>(t, tw, tb, R);
         pin();
         inv_group<1, 0>(x, ta);
         exchange<1, 0, 0>(x, half0, t);
@@ -237,14 +241,147 @@ struct SplitNtt {
     }
 };
 
-// the transform used for a shape: the split schedule where a wave holds a whole polynomial at 16 coefficients per lane
-template <int LOGN, int LL, bool SPLIT = (LL == 6 && LOGN - LL == 4)>
+// Negacyclic NTT of one polynomial of size 2M held by TWO wavefronts (M = 1024: N = 2048), as one butterfly stage across
+// the pair plus one wave-private SplitNtt of size M per wave.
+//
+// The first Cooley-Tukey stage (registers m and m+8 of the natural layout: register m of thread t = coefficient
+// t + 128 m) splits the polynomial into two independent size-M transforms hanging from nodes 2 and 3 of the twiddle tree.
+// Wave h takes half h: ONE trip through LDS re-deals the values (every thread writes its eight entries of each half,
+// wave h reads half h in SplitNtt's layout -- register m' of lane l = entry l + 64 m'), two workgroup barriers; everything
+// after that is wave-private (no barrier, the split schedule of SplitNtt hides its own LDS latency).  The generic
+// two-wave transform (PolyNtt<11,7>) needs four barriers per transform, spilled 35-54 registers inside the blind
+// rotation and conflicted in LDS; this one has the register budget of the N = 1024 kernel.
+// The inverse is the mirror image.  `bufs` of the exchange state is the polynomial's N-word LDS region; wave h uses
+// words [h M, (h+1) M) of it as its private SplitNtt buffer -- the very words only it reads in the re-deal, so no barrier is
+// needed between the re-deal and the private transform.
+// Twiddles: `uniform` is the table of the whole polynomial (N entries, tw[i] = psi^bitrev(i)); `lane` points at the two
+// halves' OWN tables back to back, M entries each: entry i of half h = entry ((2 + h) << d) + (i - 2^d) of the big table,
+// d = floor(log2 i) (host_twiddles appends them to the big table: LANE_TABLE_OFFSET).
+template <int LOGN>
+struct PairNtt {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int LL = 7;
+    static constexpr int LANES = 128;
+    static constexpr int E = N / LANES;
+    static constexpr int EH = E / 2;
+    static constexpr int M = N / 2;
+    using Half = SplitNtt<LOGN - 1, 6>;
+    static_assert(E == 16 && Half::E == 16, "two waves, 16 coefficients per lane");
+    static constexpr int LANE_TABLE_OFFSET = N;   // where the per-lane table starts inside the uploaded twiddle buffer
+    __device__ static __forceinline__ Twiddles half_table(const Twiddles &tw, uint32_t w) {
+        Twiddles sub = tw;
+        sub.lane = tw.lane + w * (uint32_t)M;
+        return sub;
+    }
+
+    struct Xchg {
+        double *bufs;
+        uint32_t pp;
+        uint32_t stride = N;
+        __device__ __forceinline__ double *next() {
+            double *b = bufs + (pp ? stride : 0);
+            pp ^= 1u;
+            return b;
+        }
+    };
+    __device__ static __forceinline__ void sync() { __syncthreads(); }
+    __host__ __device__ static constexpr uint32_t key_word(uint32_t t, int m) {
+        return (((uint32_t)(m >> 1) * LANES + t) << 1) | (uint32_t)(m & 1);
+    }
+    template <int G>
+    __device__ static __forceinline__ uint32_t index_of(uint32_t t, int m) {
+        static_assert(G == 0, "only the coefficient-domain layout is public");
+        return t + (uint32_t)LANES * (uint32_t)m;
+    }
+    // Where thread t parks register m of a polynomial handed over between the two components: inside the words its own wave
+    // uses privately afterwards, so that no other wave has to be waited for before the inverse transform starts.
+    __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (t >> 6) * (uint32_t)M + (t & 63u) + 64u * (uint32_t)m; }
+    // which half this wave owns (wave-uniform, and known to the compiler as such)
+    __device__ static __forceinline__ uint32_t wave_of(uint32_t t) { return __builtin_amdgcn_readfirstlane(t >> 6); }
+
+    struct NoHook {
+        __device__ __forceinline__ void operator()() const {}
+    };
+    template <int FIRST, class Hook>
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
+        const uint32_t w = wave_of(t), l = t & 63u;
+        {
+            const double w0 = tw.uniform[1];
+#pragma unroll
+            for (int r = 0; r < EH; r++) first_butterfly<FIRST>(x[r], x[r + EH], w0);
+        }
+        double *region = xc.bufs;
+        __syncthreads();   // whoever used the region before (the other wave's private transform, the caller) is done
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < EH; r++) region[h * M + t + (uint32_t)LANES * r] = x[h * EH + r];
+        __syncthreads();
+        double *mine = region + w * M;
+#pragma unroll
+        for (int m = 0; m < E; m++) x[m] = mine[l + 64u * m];
+        typename Half::Xchg hx{mine, 0, 0};
+        Half::template forward<0>(x, hx, l, half_table(tw, w), before_last, 2u + w);
+    }
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
+        forward<0>(x, xc, t, tw, NoHook{});
+    }
+
+    struct InvUniform {
+        typename Half::InvUniform half;
+        double w0;
+    };
+    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t t, const Twiddles &tw) {
+        InvUniform u;
+        u.half = Half::inverse_uniform(t & 63u, tw, 2u + wave_of(t));   // wave-uniform reads only: the big table
+        u.w0 = tw.uniform[1];
+        return u;
+    }
+    template <bool BOUNDED = false>
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
+        inverse<BOUNDED>(x, xc, t, tw, inverse_uniform(t, tw));
+    }
+    // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q) -> N * coefficients, |x| <= 16 q
+    template <bool BOUNDED = false>
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &uni) {
+        const uint32_t w = wave_of(t), l = t & 63u;
+        double *region = xc.bufs, *mine = region + w * M;
+        typename Half::Xchg hx{mine, 0, 0};
+        Half::template inverse<BOUNDED>(x, hx, l, half_table(tw, w), uni.half, 2u + w);   // <= 8 q, in the half's coefficient layout
+        Half::sync();      // the stores below stay behind the last reads of the private transform (same wave, same words)
+#pragma unroll
+        for (int m = 0; m < E; m++) mine[l + 64u * m] = x[m];
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < EH; r++) x[h * EH + r] = region[h * M + t + (uint32_t)LANES * r];
+        // last Gentleman-Sande stage joins the halves: inputs <= 8 q each, sums <= 16 q, products < 0.8 q
+#pragma unroll
+        for (int r = 0; r < EH; r++) {
+            const double u = x[r], v = x[r + EH];
+            x[r] = u + v;
+            x[r + EH] = fp_mulmod(u - v, uni.w0);
+        }
+    }
+};
+
+// the transform used for a shape: the split schedule where a wave holds a whole polynomial at 16 coefficients per lane,
+// the pair of split transforms where two waves hold one of twice that size
+#ifndef FBS_PAIR_NTT
+#define FBS_PAIR_NTT 1   // experiments: 0 falls back to the generic two-wave transform for N = 2048
+#endif
+template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : 0>
 struct NttFor {
     using type = PolyNtt<LOGN, LL>;
 };
 template <int LOGN, int LL>
-struct NttFor<LOGN, LL, true> {
+struct NttFor<LOGN, LL, 1> {
     using type = SplitNtt<LOGN, LL>;
+};
+template <int LOGN, int LL>
+struct NttFor<LOGN, LL, 2> {
+    using type = PairNtt<LOGN>;
 };
 
 }  // namespace fbs
