@@ -305,3 +305,28 @@ def test_noise_model_holds_for_the_n2048_set(nat):
     measured = float(np.sqrt(np.mean(err ** 2)))
     assert 0.55 * predicted < measured < 1.2 * predicted, (measured, predicted)
     assert err.max() < 0.05 * orc.Q / (4 * 31)
+
+
+def test_noise_model_holds_for_the_secure_set(nat):
+    """The 128-bit parameter set the selector returns for p = 15 at norm2 = 70 (N = 2048, one 21-bit gadget level, noise
+    at the security floor): every bootstrap decrypts, and the measured output noise is what params.variances predicts --
+    the model the selection rests on."""
+    from tfhe_fbs_map_amd.params import choose_params, margin_sigmas, security_bits, variances
+    prm = choose_params(15, 70)
+    assert security_bits(prm) >= 127.9 and margin_sigmas(prm, 70) >= 6.0
+    ctx, o = nat.Context(prm, seed=13), orc.Oracle(prm, seed=13)
+    rng = np.random.default_rng(5)
+    table = [0] + [int(v) for v in rng.integers(0, 2, 14)]
+    B = 300
+    msgs = rng.integers(0, 15, B)
+    cts = ctx.encrypt(msgs, nonce0=900)
+    out = ctx.bootstrap_batch(ctx.tvset([table]), cts)
+    assert np.array_equal(ctx.decrypt(out), [table[m] for m in msgs])
+    ref, _ = o.bootstrap_batch(cts[:3], [table])                 # the wide-digit, one-level kernel against the oracle
+    assert np.array_equal(out[:3], ref)
+    phase = o.phase(out).astype(object)
+    want = np.array([table[m] for m in msgs], dtype=object) * (2 * o.delta_half)
+    err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
+    predicted = np.sqrt(variances(prm)[0]) * orc.Q
+    measured = float(np.sqrt(np.mean(err ** 2)))
+    assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)

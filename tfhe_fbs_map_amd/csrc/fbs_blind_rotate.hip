@@ -343,6 +343,7 @@ int dev_upload_keys(fbs_ctx *ctx) {
         FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, 2 * (size_t)N * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_bsk_hat, bsk_words * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ksk, ksk_rows * ctx->ksk_stride * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_ksk_f, ksk_rows * ctx->ksk_stride * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ks_corr, (size_t)ctx->ksk_stride * 8));
     }
     // (B/2) * sum of all key rows: what turns the unsigned bit fields of the key-switch kernels into balanced digits
@@ -359,6 +360,12 @@ int dev_upload_keys(fbs_ctx *ctx) {
     FBS_HIP(ctx, hipMemsetAsync(ctx->d_ksk, 0, ksk_rows * ctx->ksk_stride * 8, ctx->stream));
     FBS_HIP(ctx, hipMemcpy2DAsync(ctx->d_ksk, (size_t)ctx->ksk_stride * 8, ctx->ksk.data(), (size_t)(p.n + 1) * 8,
                                   (size_t)(p.n + 1) * 8, ksk_rows, hipMemcpyHostToDevice, ctx->stream));
+    {   // centred doubles for the FP64 key-switch kernel, padded like the integer copy
+        std::vector<double> kf(ksk_rows * (size_t)ctx->ksk_stride, 0.0);
+        for (size_t r = 0; r < ksk_rows; r++)
+            for (uint32_t i = 0; i <= p.n; i++) kf[r * ctx->ksk_stride + i] = fq_centered(ctx->ksk[r * (p.n + 1) + i]);
+        FBS_HIP(ctx, hipMemcpy(ctx->d_ksk_f, kf.data(), kf.size() * 8, hipMemcpyHostToDevice));
+    }
     FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // fwd_c / inv_c are about to go out of scope
     switch (p.log_n_poly) {
 #define X(L) case L: return upload_keys_t<L>(ctx);

@@ -75,6 +75,7 @@ struct fbs_ctx {
     uint64_t *d_bsk_hat = nullptr;   // [n][rows][k+1][N]  NTT domain, lane-interleaved, x N^-1
     uint64_t *d_bsk_hat_small = nullptr;   // the same in the evaluation order of the small-launch shape (fbs_ntt.hpp), or null
     uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
+    uint64_t *d_ksk_f = nullptr;     // the same key as centred doubles (bit patterns), for the FP64 key-switch kernel
     uint64_t *d_ks_corr = nullptr;   // [ksk_stride]  (B/2) * sum of all key-switching-key rows: balanced digits from unsigned fields
     uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
     uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)

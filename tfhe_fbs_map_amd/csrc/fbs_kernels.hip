@@ -218,6 +218,122 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
     }
 }
 
+// The same on the FP64 pipe.  A balanced digit (|d| <= 2^(gamma-1)) times a CENTRED key word (|k| < 2^45) is exact in a
+// double, and one v_fma_f64 with the key word as its scalar operand does multiply and accumulate: one VALU instruction
+// per (digit, column, ciphertext) where the integer form needs 2.5 (v_mad_u64_u32 for the low word, a 24-bit multiply and
+// an add for the high one).  Sums stay exact below 2^53: the accumulators are centred (|.| <= q/2) every `words_per_fold`
+// mask words (chosen by the launcher so that 2^45 + words * t * 2^(44 + gamma) <= 2^53).  Measured per 1024-batch at
+// P1024: 0.66 -> 0.48 ms.  Key layout: [D*t][stride] centred doubles.
+template <int COLS, int CPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const double *__restrict__ ksk_f, uint32_t words_per_fold) {
+    constexpr int JT = 64 / WAVES;
+    constexpr int CTS = 64 * CPL;
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int TILE_WORDS = WAVES * JT * CTS > (WAVES / 2) * COLS * 2 * CTS ? WAVES * JT * CTS : (WAVES / 2) * COLS * 2 * CTS;
+    __shared__ uint32_t tile[TILE_WORDS];
+    __shared__ const uint64_t *ct_ptr[CTS];
+    static_assert(WAVES >= 2 && (WAVES & (WAVES - 1)) == 0, "tree reduction over the waves");
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t f0 = a.row0 + (size_t)blockIdx.y * CTS;
+    const uint32_t bx = blockIdx.x;   // XCD-aware column order, as in k_keyswitch_lanes
+    const uint32_t col0 = (((bx & 7u) << 1) | ((bx >> 3) & 1u) | ((bx >> 4) << 4)) * COLS;
+    if (col0 > a.n) return;
+    const uint32_t tg = a.t * a.gamma;
+    const uint32_t dmask = (1u << a.gamma) - 1u;
+    const int half_base = 1 << (a.gamma - 1);
+    const uint32_t slice_len = (a.D + WAVES - 1) / WAVES;
+
+    double acc[CPL][COLS];
+#pragma unroll
+    for (int u = 0; u < CPL; u++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) acc[u][c] = 0.0;
+    for (uint32_t q = threadIdx.x; q < CTS; q += THREADS) ct_ptr[q] = f0 + q < a.count ? ks_in(a.gv, f0 + q, a.ct_words) : nullptr;
+
+    uint32_t since_fold = 0;
+    for (uint32_t r0 = 0; r0 < slice_len; r0 += JT) {
+        __syncthreads();
+        for (uint32_t idx = threadIdx.x; idx < WAVES * JT * CTS; idx += THREADS) {
+            const uint32_t jj = idx % JT, q = (idx / JT) % CTS, sl = idx / (JT * CTS);
+            const uint32_t j = sl * slice_len + r0 + jj;
+            uint32_t v = a.offs;                                  // a missing ciphertext or word: all digits zero
+            const uint64_t *row = ct_ptr[q];
+            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg, a.offs);
+            tile[(sl * JT + jj) * CTS + q] = v;
+        }
+        __syncthreads();
+        for (uint32_t jj = 0; jj < JT; jj++) {
+            const uint32_t j = wave * slice_len + r0 + jj;
+            if (r0 + jj >= slice_len || j >= a.D) break;          // wave-uniform
+            uint32_t ab[CPL];
+#pragma unroll
+            for (int u = 0; u < CPL; u++) ab[u] = tile[(wave * JT + jj) * CTS + lane + 64 * u];
+            typedef const double __attribute__((address_space(4))) *const_doubles;   // wave-uniform, read-only: scalar loads
+            const const_doubles krow = (const_doubles)(uintptr_t)(ksk_f + (size_t)j * a.t * a.stride + col0);
+#pragma unroll 4
+            for (uint32_t v = 0; v < a.t; v++) {
+                double d[CPL];
+#pragma unroll
+                for (int u = 0; u < CPL; u++)
+                    d[u] = (double)((int)((ab[u] >> (a.gamma * (a.t - 1 - v))) & dmask) - half_base);   // balanced digit
+#pragma unroll
+                for (int c = 0; c < COLS; c++) {
+                    const double kw = krow[(size_t)v * a.stride + c];
+#pragma unroll
+                    for (int u = 0; u < CPL; u++) acc[u][c] = __builtin_fma(d[u], kw, acc[u][c]);
+                }
+            }
+            if (++since_fold == words_per_fold) {
+                since_fold = 0;
+#pragma unroll
+                for (int u = 0; u < CPL; u++)
+#pragma unroll
+                    for (int c = 0; c < COLS; c++) acc[u][c] = fp_center(acc[u][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CPL; u++)
+#pragma unroll
+        for (int c = 0; c < COLS; c++) acc[u][c] = fp_center(acc[u][c]);
+    // partial sums of the waves meet in LDS (each below q/2: eight of them stay far below 2^52)
+    double *park = reinterpret_cast<double *>(tile);
+#pragma unroll
+    for (int half = WAVES / 2; half >= 1; half /= 2) {
+        __syncthreads();
+        if (wave >= (uint32_t)half && wave < 2u * half) {
+#pragma unroll
+            for (int u = 0; u < CPL; u++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) park[((wave - half) * COLS + c) * CTS + lane + 64 * u] = acc[u][c];
+        }
+        __syncthreads();
+        if (wave < (uint32_t)half) {
+#pragma unroll
+            for (int u = 0; u < CPL; u++)
+#pragma unroll
+                for (int c = 0; c < COLS; c++) acc[u][c] += park[(wave * COLS + c) * CTS + lane + 64 * u];
+        }
+    }
+    if (wave) return;
+#pragma unroll
+    for (int u = 0; u < CPL; u++) {
+        const size_t f = f0 + lane + 64 * u;
+        if (f >= a.count) continue;
+        const uint64_t body = ct_ptr[lane + 64 * u][a.D];
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
+            const uint32_t col = col0 + c;
+            if (col > a.n) break;
+            // out = body - sum: the sum is signed here, so no correction vector
+            const uint64_t sum = fp_to_u64(fp_canon(acc[u][c]));
+            const uint64_t r = fq_sub(col == a.n ? body : 0, sum);
+            a.ms[f * (a.n + 1) + col] = (uint32_t)(((r >> (FQ_BITS - a.log2_2n - 1)) + 1) >> 1) & ((1u << a.log2_2n) - 1u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // linear combination over wire slots: out = sum coef_i * wire_i + const (exact FP64 products, lazy sum)
 // ---------------------------------------------------------------------------------------------
@@ -331,7 +447,23 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         a.cols_major = cols_major ? 1u : 0u;
         const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
         const unsigned cols_padded = cols_major ? (cols + 15u) / 16u * 16u : cols;
-        if (a.count > 64) {
+        // FP64 form: needs the centred-double copy of the key and room to accumulate at least one mask word exactly
+        const double per_word = (double)p.t_ksk * std::ldexp(1.0, 44 + (int)p.gamma_ksk);
+        const double room = std::ldexp(1.0, 53) - std::ldexp(1.0, 45);
+        static const bool allow_fp = !(getenv("FBS_KS_INTEGER") && getenv("FBS_KS_INTEGER")[0] == '1');
+        if (a.count > 64 && cols_major && allow_fp && ctx->d_ksk_f && per_word <= room) {
+            const uint32_t words_per_fold = (uint32_t)std::min(1024.0, std::floor(room / per_word));
+            const size_t tiles = (a.count + 127) / 128;
+            for (size_t t0 = 0; t0 < tiles; t0 += 65535) {
+                const unsigned nt = (unsigned)std::min<size_t>(65535, tiles - t0);
+                a.row0 = t0 * 128;
+                // measured per 1024-batch: 8 columns x 128 ciphertexts x 8 waves 0.48 ms; 16 columns 0.77 (8 waves) / 0.67 (4 waves);
+                // 8 columns x 4 waves 0.60; 256 ciphertexts 0.57
+                ctx->prof.kernel[0] = "k_keyswitch_fp<8,2,8>";
+                hipLaunchKernelGGL((k_keyswitch_fp<COLS, 2, 8>), dim3(cols_padded, nt), dim3(512), 0, stream, a,
+                                   reinterpret_cast<const double *>(ctx->d_ksk_f), words_per_fold);
+            }
+        } else if (a.count > 64) {
             const size_t tiles = (a.count + 127) / 128;
             const size_t per_launch = cols_major ? 65535 : 0x7FFFFFFF;     // tiles sit on grid.y in the column-major form
             for (size_t t0 = 0; t0 < tiles; t0 += per_launch) {
