@@ -154,6 +154,7 @@ def params_record(prm):
     from tfhe_fbs_map_amd import MODULUS
     from tfhe_fbs_map_amd.params import margin_sigmas, security_bits
     return dict(n=prm.n, N=prm.N, k=prm.k, l=prm.l_bsk, beta=prm.beta_bsk, t=prm.t_ksk, gamma=prm.gamma_ksk, p=prm.p_msg,
+                key_bits_per_step=prm.bsk_group,
                 sigma_lwe=prm.sigma_lwe, sigma_glwe=prm.sigma_glwe,
                 log2_sigma_lwe_over_q=round(math.log2(prm.sigma_lwe / MODULUS), 2),
                 log2_sigma_glwe_over_q=round(math.log2(prm.sigma_glwe / MODULUS), 2),
@@ -266,18 +267,25 @@ def run_batch(args, rank, world, local, dist):
 
 def secure_leg(B, local, steps):
     """The same batch at the parameter set `choose_params` returns for p = 15 at norm2 = 70 (the 16x16 multiplier's and
-    the adder's linear combinations), 128-bit noise, 6 sigma: what a deployment would run."""
+    the adder's linear combinations), 128-bit noise, 6 sigma: what a deployment would run.  The selector takes two key bits
+    per blind-rotation step there (bsk_group = 2); the one-bit-per-step choice is timed beside it."""
     from tfhe_fbs_map_amd import Context, choose_params
     from tfhe_fbs_map_amd.params import bootstrap_cost, margin_sigmas
-    prm = choose_params(15, 70)
-    ctx = Context(prm, seed=1, device=local)
-    elapsed, prof, *_, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
-    br, ks = prof["blind_rotate"], prof["keyswitch"]
-    rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok, params=params_record(prm),
-               margin_sigmas_at_norm2_70=round(margin_sigmas(prm, 70), 2), modelled_cost_vs_p1024=round(bootstrap_cost(prm), 3),
-               blind_rotate_kernel=br["kernel"], blind_rotate_avg_launch_ms=br["ms"] / max(1, br["launches"]),
-               keyswitch_avg_launch_ms=ks["ms"] / max(1, ks["launches"]))
-    ctx.close()
+
+    def one(prm):
+        ctx = Context(prm, seed=1, device=local)
+        elapsed, prof, *_, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
+        br, ks = prof["blind_rotate"], prof["keyswitch"]
+        rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok, params=params_record(prm),
+                   margin_sigmas_at_norm2_70=round(margin_sigmas(prm, 70), 2), modelled_cost_vs_p1024=round(bootstrap_cost(prm), 3),
+                   blind_rotate_kernel=br["kernel"], blind_rotate_avg_launch_ms=br["ms"] / max(1, br["launches"]),
+                   keyswitch_avg_launch_ms=ks["ms"] / max(1, ks["launches"]))
+        ctx.close()
+        return rec
+
+    rec = one(choose_params(15, 70))
+    if rec["params"]["key_bits_per_step"] != 1:
+        rec["one_key_bit_per_step"] = one(choose_params(15, 70, groups=(1,)))
     return rec
 
 

@@ -55,6 +55,10 @@ typedef struct fbs_params {
     uint32_t p_msg;      /* plaintext modulus p = fbs_size                        */
     uint64_t sigma_lwe;  /* std-dev of key-switch-key noise, in units of 1/q       */
     uint64_t sigma_glwe; /* std-dev of bootstrap-key and fresh-input noise, same  */
+    uint32_t bsk_group;  /* key bits consumed per blind-rotation step: 0 or 1 = one   */
+                         /* (n CMUX steps); 2 = two ("multi-bit": n/2 steps on a     */
+                         /* bundle of three GGSW samples per pair of key bits; n even)*/
+    uint32_t reserved;   /* 0                                                       */
 } fbs_params;
 
 /* Polynomial sizes.  fbs_params carries log2 N: the ring is Z_q[X]/(X^N + 1) with N a power of two (this build:
@@ -88,7 +92,8 @@ const char *fbs_device_info(const fbs_ctx *ctx);
  * the key-switching key. */
 int fbs_keygen(fbs_ctx *ctx);
 /* word counts of { sk_lwe, sk_glwe, bsk, ksk } in the standard (coefficient)
- * layout  bsk[n][(k+1)l][k+1][N],  ksk[kN][t][n+1] */
+ * layout  bsk[G][(k+1)l][k+1][N],  ksk[kN][t][n+1];  G = n GGSW samples, or with
+ * bsk_group = 2 three per pair (s0, s1) of key bits -- of s0(1-s1), (1-s0)s1, s0 s1 -- G = 3n/2 */
 int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]);
 /* test hook: copy keys out (any pointer may be NULL) so a checker can be keyed identically */
 int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk);

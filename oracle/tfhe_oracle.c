@@ -284,7 +284,7 @@ static uint64_t round_div_q(uint64_t denom_log2) { /* round(q / 2^e) */
 
 orc_ctx *orc_create(const orc_params *p, uint64_t seed) {
     if (!p || p->l_bsk * p->beta_bsk > ORC_QBITS - 2 || p->t_ksk * p->gamma_ksk > ORC_QBITS - 2 || p->l_bsk > 16 || p->t_ksk > 64 ||
-        p->log_n_poly < 2 || p->log_n_poly > 14 || p->k < 1 || p->p_msg < 1)
+        p->log_n_poly < 2 || p->log_n_poly > 14 || p->k < 1 || p->p_msg < 1 || p->bsk_group > 2 || (p->bsk_group == 2 && (p->n & 1)))
         return NULL;
     orc_ctx *c = calloc(1, sizeof *c);
     c->p = *p;
@@ -314,7 +314,19 @@ const uint64_t *orc_sk_glwe(const orc_ctx *c) { return c->sk_glwe; }
 const uint64_t *orc_bsk(const orc_ctx *c) { return c->bsk; }
 const uint64_t *orc_ksk(const orc_ctx *c) { return c->ksk; }
 
-static size_t bsk_words(const orc_ctx *c) { return (size_t)c->p.n * c->rows * (c->p.k + 1) * c->N; }
+/* GGSW samples in the bootstrapping key: one per key bit, or three per pair of key bits (bsk_group = 2) */
+static size_t n_ggsw(const orc_ctx *c) { return c->p.bsk_group == 2 ? (size_t)c->p.n / 2 * 3 : c->p.n; }
+/* the bit GGSW sample g encrypts */
+static uint64_t ggsw_bit(const orc_ctx *c, size_t g) {
+    if (c->p.bsk_group != 2) return c->sk_lwe[g];
+    uint64_t s0 = c->sk_lwe[2 * (g / 3)], s1 = c->sk_lwe[2 * (g / 3) + 1];
+    switch (g % 3) {
+        case 0: return s0 & (1 - s1);
+        case 1: return (1 - s0) & s1;
+        default: return s0 & s1;
+    }
+}
+static size_t bsk_words(const orc_ctx *c) { return n_ggsw(c) * c->rows * (c->p.k + 1) * c->N; }
 static size_t ksk_words(const orc_ctx *c) { return (size_t)c->big_n * c->p.t_ksk * (c->p.n + 1); }
 
 static void alloc_keys(orc_ctx *c) {
@@ -326,7 +338,7 @@ static void alloc_keys(orc_ctx *c) {
     c->bsk_hat = malloc(bsk_words(c) * 8);
 }
 static void transform_bsk(orc_ctx *c) {
-    size_t polys = (size_t)c->p.n * c->rows * (c->p.k + 1);
+    size_t polys = n_ggsw(c) * c->rows * (c->p.k + 1);
     memcpy(c->bsk_hat, c->bsk, bsk_words(c) * 8);
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)polys; i++) ntt_fwd(c->plan, c->bsk_hat + (size_t)i * c->N);
@@ -362,15 +374,16 @@ void orc_keygen(orc_ctx *c) {
     uint32_t N = c->N, k = c->p.k, n = c->p.n, l = c->p.l_bsk, t = c->p.t_ksk;
     for (uint32_t i = 0; i < n; i++) c->sk_lwe[i] = orc_rand64(c->seed, STREAM(DOM_SK_LWE, 0), i) & 1;
     for (uint32_t i = 0; i < c->big_n; i++) c->sk_glwe[i] = orc_rand64(c->seed, STREAM(DOM_SK_GLWE, 0), i) & 1;
-    /* BSK_i = GGSW(sk_lwe[i]): row (cc,lv) = GLWE(0) + s_i * g_lv on component cc */
+    /* BSK_g = GGSW(bit g): row (cc,lv) = GLWE(0) + bit * g_lv on component cc */
     size_t row_words = (size_t)(k + 1) * N;
 #pragma omp parallel for schedule(dynamic, 8)
-    for (long r = 0; r < (long)((size_t)n * c->rows); r++) {
-        uint32_t i = (uint32_t)(r / c->rows), rr = (uint32_t)(r % c->rows);
+    for (long r = 0; r < (long)(n_ggsw(c) * c->rows); r++) {
+        size_t g = (size_t)r / c->rows;
+        uint32_t rr = (uint32_t)(r % c->rows);
         uint32_t cc = rr / l, lv = rr % l;
         uint64_t *row = c->bsk + (size_t)r * row_words;
         glwe_encrypt_zero(c, STREAM(DOM_BSK_MASK, r), STREAM(DOM_BSK_NOISE, r), row);
-        if (c->sk_lwe[i]) row[(size_t)cc * N] = gl_add(row[(size_t)cc * N], c->g[lv]);
+        if (ggsw_bit(c, g)) row[(size_t)cc * N] = gl_add(row[(size_t)cc * N], c->g[lv]);
     }
     /* KSK[j][v] = LWE_small( sk_glwe[j] * h_v ) */
 #pragma omp parallel for schedule(dynamic, 64)
@@ -548,7 +561,70 @@ static void decompose_poly(const orc_ctx *c, const int64_t *poly, uint64_t *digi
 /* centred representative in [-(q-1)/2, (q-1)/2] */
 static inline int64_t centred(uint64_t a) { return a > ORC_Q / 2 ? (int64_t)a - (int64_t)ORC_Q : (int64_t)a; }
 
+/* Two key bits per step ("multi-bit" blind rotation, group size 2):
+ *     X^(a0 s0 + a1 s1) - 1 = s0(1-s1)(X^a0 - 1) + (1-s0)s1(X^a1 - 1) + s0 s1 (X^(a0+a1) - 1),
+ * so with GGSW samples E0, E1, E2 of the three products,
+ *     ACC += [ (X^a0 - 1) E0 + (X^a1 - 1) E1 + (X^(a0+a1) - 1) E2 ]  (x)  ACC :
+ * the bundle in brackets is a linear combination of GGSW samples by known polynomials (built here in the NTT domain,
+ * where multiplying by a polynomial is pointwise), and ACC ITSELF is decomposed -- there is no rotate-and-subtract.
+ * Half as many external products for 1.5x the key; the key-noise term of a step triples. */
+static void blind_rotate_pairs(const orc_ctx *c, const uint32_t *ms, const uint64_t *tv, uint64_t *acc) {
+    uint32_t N = c->N, k = c->p.k, n = c->p.n, l = c->p.l_bsk;
+    uint32_t comps = k + 1, twoN = 2 * N;
+    int64_t *cen = malloc((size_t)N * 8);
+    uint64_t *dig = malloc((size_t)l * N * 8);
+    uint64_t *sum = malloc((size_t)comps * N * 8);
+    uint64_t *mono = malloc((size_t)3 * N * 8);
+    memset(acc, 0, (size_t)k * N * 8);
+    poly_rotate(tv, acc + (size_t)k * N, (twoN - ms[n]) & (twoN - 1), N); /* X^{-b~} * TV */
+    for (uint32_t i = 0; i < n / 2; i++) {
+        uint32_t e[3] = {ms[2 * i], ms[2 * i + 1], (ms[2 * i] + ms[2 * i + 1]) & (twoN - 1)};
+        if (e[0] == 0 && e[1] == 0) continue; /* the bundle is zero */
+        for (uint32_t jj = 0; jj < 3; jj++) { /* X^e - 1 as a polynomial, then its transform */
+            uint64_t *m = mono + (size_t)jj * N;
+            memset(m, 0, (size_t)N * 8);
+            if (e[jj]) {
+                m[0] = Q - 1;
+                uint32_t pos = e[jj] & (N - 1);
+                m[pos] = gl_add(m[pos], e[jj] < N ? 1 : Q - 1);
+            }
+            ntt_fwd(c->plan, m);
+        }
+        memset(sum, 0, (size_t)comps * N * 8);
+        for (uint32_t cc = 0; cc < comps; cc++) {
+            for (uint32_t j = 0; j < N; j++) cen[j] = centred(acc[(size_t)cc * N + j]);
+            decompose_poly(c, cen, dig);
+            for (uint32_t lv = 0; lv < l; lv++) {
+                uint64_t *dh = dig + (size_t)lv * N;
+                ntt_fwd(c->plan, dh);
+                for (uint32_t oc = 0; oc < comps; oc++)
+                    for (uint32_t j = 0; j < N; j++) {
+                        uint64_t kw = 0;
+                        for (uint32_t jj = 0; jj < 3; jj++) {
+                            const uint64_t *row = c->bsk_hat + ((((size_t)i * 3 + jj) * c->rows) + cc * l + lv) * comps * N;
+                            kw = gl_add(kw, gl_mul(mono[(size_t)jj * N + j], row[(size_t)oc * N + j]));
+                        }
+                        sum[(size_t)oc * N + j] = gl_add(sum[(size_t)oc * N + j], gl_mul(dh[j], kw));
+                    }
+            }
+        }
+        for (uint32_t oc = 0; oc < comps; oc++) {
+            uint64_t *s = sum + (size_t)oc * N;
+            ntt_inv(c->plan, s);
+            for (uint32_t j = 0; j < N; j++) acc[(size_t)oc * N + j] = gl_add(acc[(size_t)oc * N + j], s[j]);
+        }
+    }
+    free(cen);
+    free(dig);
+    free(sum);
+    free(mono);
+}
+
 void orc_blind_rotate(const orc_ctx *c, const uint32_t *ms, const uint64_t *tv, uint64_t *acc) {
+    if (c->p.bsk_group == 2) {
+        blind_rotate_pairs(c, ms, tv, acc);
+        return;
+    }
     uint32_t N = c->N, k = c->p.k, n = c->p.n, l = c->p.l_bsk;
     uint32_t comps = k + 1, twoN = 2 * N;
     uint64_t *rot = malloc((size_t)N * 8);

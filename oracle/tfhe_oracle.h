@@ -56,6 +56,8 @@ typedef struct {
     uint32_t p_msg;      /* plaintext modulus p ("fbs_size"): Delta=q/2p */
     uint64_t sigma_lwe;  /* noise std-dev (absolute, units of 1/q) KSK   */
     uint64_t sigma_glwe; /* noise std-dev for BSK rows and fresh inputs  */
+    uint32_t bsk_group;  /* key bits per blind-rotation step: 0/1 = one, 2 = two (n even) */
+    uint32_t reserved;
 } orc_params;
 
 typedef struct orc_ctx orc_ctx;
@@ -78,7 +80,9 @@ void     orc_destroy(orc_ctx *c);
 /* generate keys from the seed (same derivation as the product's fbs_keygen) */
 void     orc_keygen(orc_ctx *c);
 /* or install keys exported by the product (coefficient-domain BSK):
- *   sk_lwe[n], sk_glwe[k*N] (0/1), bsk[n][(k+1)l][k+1][N], ksk[kN][t][n+1] */
+ *   sk_lwe[n], sk_glwe[k*N] (0/1), bsk[G][(k+1)l][k+1][N], ksk[kN][t][n+1]
+ * G GGSW samples: n of them (one per key bit) when bsk_group <= 1; with bsk_group = 2 three per PAIR of key bits
+ * (s0, s1) = (sk[2i], sk[2i+1]), encrypting s0(1-s1), (1-s0)s1, s0 s1 in this order: G = 3n/2 */
 void     orc_set_keys(orc_ctx *c, const uint64_t *sk_lwe, const uint64_t *sk_glwe,
                       const uint64_t *bsk, const uint64_t *ksk);
 const uint64_t *orc_sk_lwe(const orc_ctx *c);

@@ -24,7 +24,7 @@ def build(force=False):
 class _P(C.Structure):
     _fields_ = [(f, C.c_uint32) for f in
                 ("n", "log_n_poly", "k", "l_bsk", "beta_bsk", "t_ksk", "gamma_ksk", "p_msg")] + \
-               [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64)]
+               [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64), ("bsk_group", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -88,10 +88,14 @@ class Oracle:
     def __init__(self, params, seed=1, keygen=True):
         get = (lambda f: params[f]) if isinstance(params, dict) else (lambda f: getattr(params, f))
         self.p = {f: int(get(f)) for f in self.FIELDS}
+        try:
+            self.group = int(get("bsk_group"))
+        except (KeyError, AttributeError):
+            self.group = 1
         self.N = 1 << self.p["log_n_poly"]
         self.D = self.p["k"] * self.N
         self.ctw = self.D + 1
-        cp = _P(**self.p)
+        cp = _P(bsk_group=self.group, reserved=0, **self.p)
         self._h = lib().orc_create(C.byref(cp), seed)
         if not self._h:
             raise ValueError("oracle rejected the parameter set")
@@ -105,7 +109,8 @@ class Oracle:
 
     def key_sizes(self):
         p = self.p
-        return (p["n"], self.D, p["n"] * (p["k"] + 1) * p["l_bsk"] * (p["k"] + 1) * self.N,
+        ggsw = p["n"] // 2 * 3 if self.group == 2 else p["n"]
+        return (p["n"], self.D, ggsw * (p["k"] + 1) * p["l_bsk"] * (p["k"] + 1) * self.N,
                 self.D * p["t_ksk"] * (p["n"] + 1))
 
     def keys(self):

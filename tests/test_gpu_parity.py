@@ -312,7 +312,7 @@ def test_noise_model_holds_for_the_secure_set(nat):
     at the security floor): every bootstrap decrypts, and the measured output noise is what params.variances predicts --
     the model the selection rests on."""
     from tfhe_fbs_map_amd.params import choose_params, margin_sigmas, security_bits, variances
-    prm = choose_params(15, 70)
+    prm = choose_params(15, 70, groups=(1,))                     # one key bit per step
     assert security_bits(prm) >= 127.9 and margin_sigmas(prm, 70) >= 6.0
     ctx, o = nat.Context(prm, seed=13), orc.Oracle(prm, seed=13)
     rng = np.random.default_rng(5)
@@ -329,4 +329,58 @@ def test_noise_model_holds_for_the_secure_set(nat):
     err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
     predicted = np.sqrt(variances(prm)[0]) * orc.Q
     measured = float(np.sqrt(np.mean(err ** 2)))
+    assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)
+
+
+@pytest.mark.parametrize("log_n", [10, 11])
+@pytest.mark.parametrize("l,beta", [(1, 20), (1, 8), (3, 7), (2, 10), (5, 5)])
+def test_two_key_bits_per_step_bit_exact(nat, toy_params, log_n, l, beta):
+    """bsk_group = 2 (k_blind_rotate_pairs: the bundle of three GGSW samples per pair of key bits, built in the NTT
+    domain from a table of psi^x in LDS): keys, ciphertexts and decryptions identical to the oracle's, at both polynomial
+    sizes it is built for and across gadget shapes (one-level, two-FMA and general variants)."""
+    prm = toy_params.replace(log_n_poly=log_n, l_bsk=l, beta_bsk=beta, bsk_group=2)
+    ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
+    mine, theirs = ctx.export_keys(), o.keys()
+    for k in mine:
+        assert np.array_equal(mine[k], theirs[k]), k
+    msgs = np.concatenate([np.arange(len(t)) for t in MODES])
+    ids = np.concatenate([np.full(len(t), i) for i, t in enumerate(MODES)]).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=11)
+    got = ctx.bootstrap_batch(ctx.tvset(MODES), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, MODES, ids)
+    assert np.array_equal(got, ref)
+    if l * beta >= 20:
+        assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(t) for t in MODES]))
+
+
+def test_two_key_bits_per_step_rejections(nat, toy_params):
+    for bad in (toy_params.replace(bsk_group=2, n=13), toy_params.replace(bsk_group=2, log_n_poly=9),
+                toy_params.replace(bsk_group=3), toy_params.replace(bsk_group=2, l_bsk=6, beta_bsk=4)):
+        with pytest.raises(nat.FbsError) as e:
+            nat.Context(bad, seed=1)
+        assert e.value.code == -1
+
+
+def test_noise_model_holds_with_two_key_bits_per_step(nat):
+    """The selector's 128-bit choice for p = 15 at norm2 = 70 takes two key bits per step; its measured bootstrap output
+    noise against params.variances (the key-noise term of a step triples, the rounding term grows by half)."""
+    from tfhe_fbs_map_amd.params import choose_params, margin_sigmas, security_bits, variances
+    prm = choose_params(15, 70)
+    assert prm.bsk_group == 2 and prm.l_bsk == 1 and security_bits(prm) >= 127.9 and margin_sigmas(prm, 70) >= 6.0
+    ctx, o = nat.Context(prm, seed=17), orc.Oracle(prm, seed=17)
+    rng = np.random.default_rng(6)
+    table = [0] + [int(v) for v in rng.integers(0, 2, 14)]
+    B = 300
+    msgs = rng.integers(0, 15, B)
+    cts = ctx.encrypt(msgs, nonce0=900)
+    out = ctx.bootstrap_batch(ctx.tvset([table]), cts)
+    assert np.array_equal(ctx.decrypt(out), [table[m] for m in msgs])
+    ref, _ = o.bootstrap_batch(cts[:3], [table])
+    assert np.array_equal(out[:3], ref)
+    phase = o.phase(out).astype(object)
+    want = np.array([table[m] for m in msgs], dtype=object) * (2 * o.delta_half)
+    err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
+    predicted = np.sqrt(variances(prm)[0]) * orc.Q
+    measured = float(np.sqrt(np.mean(err ** 2)))
+    print("two bits per step: measured %.3g predicted %.3g" % (measured, predicted))
     assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)

@@ -110,12 +110,15 @@ def test_lincomb_and_stages(toy):
 @pytest.mark.parametrize("name,T", [("demo_fbs_exec_env", 2), ("edge_outputs", 6), ("edge_nomerge", 6),
                                     ("full_adder__search_p7", 8), ("aoi21__naive_p7", 8), ("adder8__search_p7", 3),
                                     ("ascon_lut__search_p7", 2)])
-def test_homomorphic_program_matches_reference_golden(toy_params, name, T):
+@pytest.mark.parametrize("group", [1, 2])
+def test_homomorphic_program_matches_reference_golden(toy_params, name, T, group):
+    """The decrypted level is what pins the encrypted path to the reference: with one key bit per blind-rotation step and
+    with two (bsk_group = 2, the multi-bit form), programs decrypt to the reference's cleartext goldens."""
     rec = load_fixture(name)
     ops, outs = lut_oracle.read_fbs(rec["fbs"])
     tables = [op[3] for op in ops if op[0] == "boot"]
     p = max(7, max((len(t) for t in tables), default=2))        # generous p: every table fits the half torus
-    o = orc.Oracle(toy_params.replace(log_n_poly=9, p_msg=p), seed=3)
+    o = orc.Oracle(toy_params.replace(log_n_poly=9, p_msg=p, bsk_group=group), seed=3)
     ins, expect = subsample(rec, T)
     cts = {k: o.encrypt(v, nonce0=1000 * i) for i, (k, v) in enumerate(ins.items())}
     wires = oracle_eval_program(o, ops, outs, cts)
@@ -125,3 +128,20 @@ def test_homomorphic_program_matches_reference_golden(toy_params, name, T):
             assert e == int(src)
         else:
             assert np.array_equal(o.decrypt(wires[src]), e), out_name
+
+
+@pytest.mark.parametrize("l,beta", [(1, 20), (3, 7)])
+def test_two_key_bits_per_step_every_table_mode(toy_params, l, beta):
+    """bsk_group = 2: all table modes of the negacyclic contract, multi-valued tables, both gadget shapes; the key holds
+    three GGSW samples per pair of key bits."""
+    prm = toy_params.replace(log_n_poly=9, l_bsk=l, beta_bsk=beta, bsk_group=2)
+    o = orc.Oracle(prm, seed=5)
+    assert o.key_sizes()[2] == prm.n // 2 * 3 * 2 * l * 2 * 512
+    tables = [[0, 1, 1, 0, 1, 0, 0], [0, 1, 2, 3, 2, 1, 0], [0, 1], [0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1],
+              [0, 0, 0, 1, 1, 0, 1, 0, 0, 0], [1, 1, 1, 0, 0, 1, 0, 1, 1, 1]]
+    msgs = np.concatenate([np.arange(len(t)) for t in tables])
+    ids = np.concatenate([np.full(len(t), i) for i, t in enumerate(tables)]).astype(np.uint32)
+    out, _ = o.bootstrap_batch(o.encrypt(msgs, nonce0=5), tables, ids)
+    assert np.array_equal(o.decrypt(out), np.concatenate([np.array(t) for t in tables]))
+    with pytest.raises(ValueError):
+        orc.Oracle(prm.replace(n=prm.n + 1), seed=5)            # pairs need an even n

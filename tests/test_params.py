@@ -83,6 +83,18 @@ def test_cost_ranking_against_the_references_points():
     assert abs(bootstrap_cost(P1024) - 1.0) < 1e-9 and bootstrap_cost(P2048) > 1.5
 
 
+def test_two_key_bits_per_step_is_chosen_where_it_pays():
+    """bsk_group = 2 halves the blind-rotation steps at 3x the key-noise term: the selector takes it for one-level gadgets at
+    N = 2048 (measured 0.81 of the one-bit cost) and keeps one bit per step where more levels are needed."""
+    a, b = choose_params(15, 70), choose_params(15, 70, groups=(1,))
+    assert a.bsk_group == 2 and a.l_bsk == 1 and a.n % 2 == 0 and b.bsk_group == 1
+    assert bootstrap_cost(a) < bootstrap_cost(b) and margin_sigmas(a, 70) >= 6.0
+    va, vb = variances(a)[0], variances(a.replace(bsk_group=1))[0]
+    assert 1.4 < va / vb < 3.1                                  # between the rounding term's 1.5x and the key term's 3x
+    assert choose_params(2, 1).bsk_group == 1 and choose_params(4, 2).bsk_group == 1
+    assert a.bytes_per_fbs() > b.replace(n=a.n).bytes_per_fbs()  # 1.5x the bootstrapping key
+
+
 def test_reduced_noise_search_and_error_probability():
     """security=None: the same search at a fixed (benchmark) noise."""
     c = choose_params(15, 84, security=None)

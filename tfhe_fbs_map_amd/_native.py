@@ -27,7 +27,7 @@ class FbsError(RuntimeError):
 class _Params(C.Structure):
     _fields_ = [(f, C.c_uint32) for f in
                 ("n", "log_n_poly", "k", "l_bsk", "beta_bsk", "t_ksk", "gamma_ksk", "p_msg")] + \
-               [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64)]
+               [("sigma_lwe", C.c_uint64), ("sigma_glwe", C.c_uint64), ("bsk_group", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _Layout(C.Structure):
@@ -60,6 +60,7 @@ class Params:
     p_msg: int = 15
     sigma_lwe: int | None = None      # key-switching-key noise, absolute units of 1/q
     sigma_glwe: int | None = None     # bootstrapping-key and fresh-input noise
+    bsk_group: int = 1                # key bits per blind-rotation step: 1, or 2 (n/2 steps on bundles of 3 GGSW samples)
 
     def __post_init__(self):
         if self.sigma_lwe is None:
@@ -99,7 +100,7 @@ class Params:
         return Params(**d)
 
     def to_c(self):
-        return _Params(**asdict(self))
+        return _Params(reserved=0, **asdict(self))
 
     def bytes_per_fbs(self):
         """Algorithmic bytes one FBS must consume: every
@@ -107,7 +108,7 @@ class Params:
         output ciphertext and its test vector."""
         N, k, n = self.N, self.k, self.n
         ggsw = (k + 1) * self.l_bsk * (k + 1) * N * 8
-        bsk = n * ggsw
+        bsk = (n // 2 * 3 if self.bsk_group == 2 else n) * ggsw
         ksk = k * N * self.t_ksk * (n + 1) * 8
         return bsk + ksk + 2 * (k * N + 1) * 8 + N * 8
 

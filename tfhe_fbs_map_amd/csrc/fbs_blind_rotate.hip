@@ -31,6 +31,7 @@ struct BrArgs {
     const uint64_t *post;    // [tables]
     uint32_t n, l, beta, ct_words, n_tables;
     size_t count;            // bootstraps in this launch
+    const double *psi_pow;   // [N] psi^x, centred (two key bits per step only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -289,6 +290,234 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two key bits per step ("multi-bit" blind rotation, bsk_group = 2).  With E0, E1, E2 the GGSW samples of s0(1-s1),
+// (1-s0)s1, s0 s1 for a pair (s0, s1) of key bits and (a0, a1) the pair's rotation amounts,
+//     ACC += [ (X^a0 - 1) E0 + (X^a1 - 1) E1 + (X^(a0+a1) - 1) E2 ]  (x)  ACC.
+// The bundle in brackets is built in the NTT domain, where X^e - 1 is the pointwise factor zeta^e - 1 (zeta = the
+// evaluation point a register holds = psi^(2 bitrev(P) + 1) at array position P; looked up in a table of psi^x - 1), and
+// ACC itself is decomposed: no rotate-and-subtract step, no LDS round trip for it, and HALF the transforms per key bit.
+// Costs: three key polynomials read and three exact products per key word built (per pair of bits), 1.5x the key, and a
+// step's key-noise term triples (params.variances).  Same shapes, layouts and transforms as k_blind_rotate; DIG as there
+// (0, 3 and 4 are built).
+template <int LOGN, int LL, int DIG>
+__global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate_pairs(BrArgs a) {
+    using W = typename NttFor<LOGN, LL>::type;
+    static_assert(W::HAS_EVAL_POSITION, "the bundle needs to know which evaluation point a register holds");
+    constexpr int N = W::N, E = W::E, LANES = W::LANES;
+    constexpr int FIRST = DIG == 3 ? 2 : 0;
+    constexpr bool ONE_LEVEL = DIG == 4;
+    // [component][exchange buffer | twiddle table][N], then psi^x for x < N (psi^(x+N) = -psi^x): 5 N words = 40 KB at
+    // N = 1024, 80 KB at N = 2048 -- exactly what lets 8 waves share a CU's 160 KB
+    __shared__ double lds_all[2 * 2 * N + N];
+    const uint32_t comp = (threadIdx.x >> LL) & 1u;
+    const uint32_t t = threadIdx.x & (LANES - 1);
+    double *lds = lds_all;
+    double *mine = lds + comp * 2 * N;
+    double *theirs = lds + (comp ^ 1u) * 2 * N;
+    const char *psi = reinterpret_cast<const char *>(lds + 4 * N);
+    typename W::Xchg xc{mine, 0};
+    Twiddles twf(a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_fwd), twi(a.tw_inv + W::LANE_TABLE_OFFSET, a.tw_inv);
+    static_assert(LL <= FBS_ONE_BUFFER_MAX_LL, "one exchange buffer per polynomial, twiddle tables beside it");
+    {
+        xc.stride = 0;
+        double *table = mine + N;
+        const double *src = (comp ? a.tw_inv : a.tw_fwd) + W::LANE_TABLE_OFFSET;
+#pragma unroll
+        for (int m = 0; m < E; m++) table[t + (uint32_t)LANES * m] = src[t + (uint32_t)LANES * m];
+#pragma unroll
+        for (int m = 0; m < E / 2; m++) {   // the two components' threads copy half of the psi table each
+            const uint32_t x = comp * (N / 2) + t + (uint32_t)LANES * m;
+            lds[4 * N + x] = a.psi_pow[x];
+        }
+        __syncthreads();
+        twf.lane = lds + N;
+        twi.lane = lds + 3 * N;
+    }
+
+    const bool live = (size_t)blockIdx.x < a.count;
+    const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
+    size_t gate, ms_row;
+    gate_of(a.gv, f, &gate, &ms_row);
+    uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    if (table >= a.n_tables) table = 0;
+    const uint32_t *ms = a.ms + ms_row * (a.n + 1);
+    const uint64_t *tv = a.tvs + (size_t)table * N;
+    const uint32_t rows = 2 * a.l;
+
+    double acc[E];   // ACC = (0, X^{-b~} * TV), centred; register m of lane t = coefficient t + LANES*m
+    {
+        const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
+            const uint64_t v = tv[idx & (N - 1)];
+            acc[m] = comp ? fp_center(fp_from_u64((idx & N) ? fq_neg(v) : v)) : 0.0;
+        }
+    }
+    // rounding / digit constants: as in k_blind_rotate
+    const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.l * a.beta));
+    const uint32_t bhalf = 1u << (a.beta - 1);
+    double round_offset = 0.5 + fp_exp2i((int)(a.l * a.beta));
+    uint32_t sign_bits = 0;
+    for (uint32_t j = 0; j < a.l; j++) {
+        round_offset += (double)(bhalf << (j * a.beta));
+        sign_bits |= bhalf << (j * a.beta);
+    }
+    // zeta^e for the evaluation point zeta = psi^o a register holds: exponent e * o mod 2N, o = o_lane + c_m with
+    // o_lane = 2 bitrev(lane part of the array position) + 1 and c_m = 2 bitrev(register part), a compile-time constant.
+    // Kept times 8: bits [3, 3 + LOGN) are the byte offset into the table of psi^x, x < N, bit 3 + LOGN the sign.
+    const uint32_t o_lane8 = (2u * (__builtin_bitreverse32(W::eval_position_lane(t)) >> (32 - LOGN)) + 1u) << 3;
+    constexpr uint32_t MASK8 = (uint32_t)(N - 1) << 3;
+
+    const uint32_t n_pairs = a.n / 2;
+    uint32_t e0_next = ms[0], e1_next = ms[1];
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        uint32_t e[3];
+        e[0] = __builtin_amdgcn_readfirstlane(e0_next);
+        e[1] = __builtin_amdgcn_readfirstlane(e1_next);
+        e0_next = ms[2 * i + 2 < a.n ? 2 * i + 2 : a.n];   // (the last pair re-reads the body word and ignores it)
+        e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
+        if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the bootstrap's waves)
+        e[2] = (e[0] + e[1]) & (2u * N - 1u);
+        uint32_t lane8[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) lane8[jj] = __umul24(e[jj], o_lane8);
+
+        // ---- ACC_c itself, rounded to the closest multiple of q / B^l; packed balanced digits -------------
+        uint32_t digits[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) digits[m] = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ sign_bits;
+
+        double own[E], other[E];
+        auto level = [&](int lv, auto assign) {
+            constexpr bool ASSIGN = decltype(assign)::value;
+            const uint32_t shift = ((uint32_t)a.l - 1u - (uint32_t)lv) * a.beta;
+            double x[E];
+#pragma unroll
+            for (int m = 0; m < E; m++) x[m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);
+            // (the exponents are "redefined" here so that the 48 uniform products e * c_m below are computed where they are
+            // used, level by level, instead of being hoisted out of the level loop into more SGPRs than there are)
+            uint32_t e_lv[3] = {e[0], e[1], e[2]};
+            if constexpr (!ONE_LEVEL) asm volatile("" : "+s"(e_lv[0]), "+s"(e_lv[1]), "+s"(e_lv[2]));
+            const double2 *k_own[3], *k_oth[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++) {
+                const double *krow = a.bsk_hat + ((((size_t)i * 3 + jj) * rows + comp * a.l + lv) * 2) * N;
+                k_own[jj] = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
+                k_oth[jj] = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+            }
+            // what one register pair (2j, 2j+1) needs from memory: its words of the six key polynomials ...
+            struct PairKeys {
+                double2 ko[3], kt[3];
+            };
+            auto request = [&](auto jc, PairKeys &in) {
+                constexpr int j = decltype(jc)::value;
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                    in.ko[jj] = k_own[jj][j * LANES + t];
+                    in.kt[jj] = k_oth[jj][j * LANES + t];
+                }
+            };
+            auto consume = [&](auto jc, const PairKeys &in) {
+                constexpr int j = decltype(jc)::value;
+                // ... and zeta^e - 1 for its two registers and the three exponents, from the table of psi^x in LDS
+                double mono[3][2];
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t creg8 = (2u * (__builtin_bitreverse32(W::eval_position_reg(2 * j + u)) >> (32 - LOGN))) << 3;
+                        const uint32_t off = lane8[jj] + e_lv[jj] * creg8;
+                        const double v = *reinterpret_cast<const double *>(psi + (off & MASK8));
+                        // (+-) by the bit above the table index, then - 1
+                        const int hi = __double2hiint(v) ^ (int)((off << (31 - 3 - LOGN)) & 0x80000000u);
+                        mono[jj][u] = __hiloint2double(hi, __double2loint(v)) - 1.0;
+                    }
+                // key words of the bundle: lazy sums of three exact products (< 2.3 q).  With |x| < 2^49.3 (general first
+                // stage) the product below stays within 0.9 q as it is; the two-FMA first stage leaves |x| near 2^51 and
+                // wants the word centred first.
+                double wo0 = 0, wo1 = 0, wt0 = 0, wt1 = 0;
+#pragma unroll
+                for (int jj = 0; jj < 3; jj++) {
+                    wo0 += fp_mulmod(in.ko[jj].x, mono[jj][0]);
+                    wo1 += fp_mulmod(in.ko[jj].y, mono[jj][1]);
+                    wt0 += fp_mulmod(in.kt[jj].x, mono[jj][0]);
+                    wt1 += fp_mulmod(in.kt[jj].y, mono[jj][1]);
+                }
+                if constexpr (FIRST == 2) {
+                    wo0 = fp_center(wo0);
+                    wo1 = fp_center(wo1);
+                    wt0 = fp_center(wt0);
+                    wt1 = fp_center(wt1);
+                }
+                const double p0 = fp_mulmod(x[2 * j], wo0), p1 = fp_mulmod(x[2 * j + 1], wo1);
+                const double r0 = fp_mulmod(x[2 * j], wt0), r1 = fp_mulmod(x[2 * j + 1], wt1);
+                own[2 * j] = ASSIGN ? p0 : own[2 * j] + p0;
+                own[2 * j + 1] = ASSIGN ? p1 : own[2 * j + 1] + p1;
+                other[2 * j] = ASSIGN ? r0 : other[2 * j] + r0;
+                other[2 * j + 1] = ASSIGN ? r1 : other[2 * j + 1] + r1;
+            };
+            // The key words of pair 0 are requested before the last butterfly group of the transform; with the one-level
+            // shape there are registers to keep the words of pair j+1 in flight while pair j is consumed (vector-memory
+            // results return in order: requests must be ISSUED in the order they are consumed, hence the fences).
+#ifndef FBS_PAIRS_PIPELINE
+#define FBS_PAIRS_PIPELINE 0   // measured on the 128-bit set: 11.5 ms with the pipeline (35 registers spilled), 11.4 without
+#endif
+            constexpr bool PIPE = FBS_PAIRS_PIPELINE && ONE_LEVEL;
+            PairKeys in[PIPE ? 2 : 1];
+            W::template forward<FIRST>(x, xc, t, twf, [&] { request(std::integral_constant<int, 0>{}, in[0]); });
+            static_assert(E == 16, "eight register pairs, written out");
+#define FBS_PAIR_STEP(J)                                                                                    \
+    if constexpr (PIPE) {                                                                                   \
+        if constexpr ((J) + 1 < E / 2) {                                                                    \
+            request(std::integral_constant<int, ((J) + 1 < E / 2 ? (J) + 1 : 0)>{}, in[((J) + 1) & 1]);      \
+            __builtin_amdgcn_sched_barrier(0);                                                              \
+        }                                                                                                   \
+        consume(std::integral_constant<int, (J)>{}, in[PIPE ? ((J) & 1) : 0]);                              \
+    } else {                                                                                                \
+        if constexpr ((J) > 0) request(std::integral_constant<int, (J)>{}, in[0]);                          \
+        consume(std::integral_constant<int, (J)>{}, in[0]);                                                 \
+        if constexpr (!ONE_LEVEL) __builtin_amdgcn_sched_barrier(0);                                        \
+    }
+            FBS_PAIR_STEP(0) FBS_PAIR_STEP(1) FBS_PAIR_STEP(2) FBS_PAIR_STEP(3)
+            FBS_PAIR_STEP(4) FBS_PAIR_STEP(5) FBS_PAIR_STEP(6) FBS_PAIR_STEP(7)
+#undef FBS_PAIR_STEP
+        };
+        level((int)a.l - 1, std::true_type{});
+        if constexpr (!ONE_LEVEL)
+            for (int lv = (int)a.l - 2; lv >= 0; lv--) level(lv, std::false_type{});
+
+        // ---- hand the partner its half, inverse transform, accumulate: as in k_blind_rotate ---------------
+        const typename W::InvUniform inv_uni = W::inverse_uniform(t, twi);
+        {
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; m++) theirs[W::handoff_word(t, m)] = other[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; m++) own[m] += mine[W::handoff_word(t, m)];
+        }
+        W::template inverse<true>(own, xc, t, twi, inv_uni);   // 2l products below 0.8 q each: l <= 5 (the launcher checks)
+#pragma unroll
+        for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
+    }
+
+    if (!live) return;
+    uint64_t *out = gate_out(a.gv, f, a.ct_words);
+    if (comp == 0) {
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t j = t + (uint32_t)LANES * m;
+            const uint64_t v = fp_to_u64(fp_canon(acc[m]));
+            if (j == 0) out[0] = v;
+            else out[N - j] = fq_neg(v);
+        }
+    } else if (t == 0) {
+        out[N] = fq_add(fp_to_u64(fp_canon(acc[0])), a.post[table]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 #define FBS_FOR_EACH_SHAPE(X) X(8) X(9) X(10) X(11)
@@ -298,7 +527,7 @@ static int upload_keys_t(fbs_ctx *ctx) {
     constexpr int LL = lanes_log2_for(LOGN);
     const fbs_params &p = ctx->p;
     const uint32_t N = ctx->N;
-    const size_t polys = (size_t)p.n * ctx->rows * (p.k + 1);
+    const size_t polys = ctx->n_ggsw * ctx->rows * (p.k + 1);
     uint64_t *d_src = nullptr;
     FBS_HIP(ctx, hipMalloc(&d_src, polys * N * 8));
     hipError_t e = hipMemcpyAsync(d_src, ctx->bsk.data(), polys * N * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -336,7 +565,7 @@ int dev_upload_keys(fbs_ctx *ctx) {
         fwd_c[i] = fq_centered(fwd[i]);
         inv_c[i] = fq_centered(inv[i]);
     }
-    const size_t bsk_words = (size_t)p.n * ctx->rows * (p.k + 1) * N;
+    const size_t bsk_words = ctx->n_ggsw * ctx->rows * (p.k + 1) * N;
     const size_t ksk_rows = (size_t)ctx->D * p.t_ksk;
     if (!ctx->d_tw_fwd) {
         FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, 2 * (size_t)N * 8));
@@ -360,6 +589,17 @@ int dev_upload_keys(fbs_ctx *ctx) {
     FBS_HIP(ctx, hipMemsetAsync(ctx->d_ksk, 0, ksk_rows * ctx->ksk_stride * 8, ctx->stream));
     FBS_HIP(ctx, hipMemcpy2DAsync(ctx->d_ksk, (size_t)ctx->ksk_stride * 8, ctx->ksk.data(), (size_t)(p.n + 1) * 8,
                                   (size_t)(p.n + 1) * 8, ksk_rows, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->group == 2) {   // psi^x, x < N: what the pointwise factors zeta^e - 1 of the monomials X^e - 1 are made from
+        std::vector<double> tbl(N);
+        const uint64_t psi = fq_pow(FQ_GENERATOR, (FQ - 1) / (2ull * N));
+        uint64_t pw = 1;
+        for (uint32_t x = 0; x < N; x++) {
+            tbl[x] = fq_centered(pw);
+            pw = fq_mul(pw, psi);
+        }
+        if (!ctx->d_psi_pow) FBS_HIP(ctx, hipMalloc(&ctx->d_psi_pow, tbl.size() * 8));
+        FBS_HIP(ctx, hipMemcpy(ctx->d_psi_pow, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice));
+    }
     {   // centred doubles for the FP64 key-switch kernel, padded like the integer copy
         std::vector<double> kf(ksk_rows * (size_t)ctx->ksk_stride, 0.0);
         for (size_t r = 0; r < ksk_rows; r++)
@@ -399,6 +639,34 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
+    if (ctx->group == 2) {
+        a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
+        const int dig2 = p.l_bsk == 1 ? 4 : p.beta_bsk <= 7 ? 3 : 0;
+        hipEvent_t e0, e1;
+        prof_begin(ctx, 1, stream, &e0, &e1);
+#define LAUNCH_PAIRS(L, DIG)                                                                                          \
+    do {                                                                                                               \
+        ctx->prof.kernel[1] = "k_blind_rotate_pairs<" #L "," + std::to_string(lanes_log2_for(L)) + "," #DIG ">";        \
+        hipLaunchKernelGGL((k_blind_rotate_pairs<L, lanes_log2_for(L), DIG>), dim3((unsigned)count),                   \
+                           dim3(2 << lanes_log2_for(L)), 0, stream, a);                                                \
+    } while (0)
+#define PAIRS_FOR(L)                                                                                                   \
+    case L:                                                                                                            \
+        if (dig2 == 4) LAUNCH_PAIRS(L, 4);                                                                             \
+        else if (dig2 == 3) LAUNCH_PAIRS(L, 3);                                                                        \
+        else LAUNCH_PAIRS(L, 0);                                                                                       \
+        break;
+        switch (p.log_n_poly) {
+            PAIRS_FOR(10)
+            PAIRS_FOR(11)
+            default: return set_error(ctx, FBS_E_INVALID, "two key bits per step: N = 1024 or 2048 only");
+        }
+#undef PAIRS_FOR
+#undef LAUNCH_PAIRS
+        prof_end(ctx, 1, stream, e0, e1);
+        FBS_HIP(ctx, hipGetLastError());
+        return FBS_OK;
+    }
     const int dig = p.l_bsk > 5 ? 0 : p.l_bsk == 1 ? 4 : p.beta_bsk <= 7 ? 3 : p.beta_bsk <= 9 ? 2 : 1;
     // at most one bootstrap per CU: the shape with twice the waves per bootstrap, where there is one (fbs_ntt.hpp)
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;

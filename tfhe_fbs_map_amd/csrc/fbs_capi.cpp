@@ -142,9 +142,13 @@ int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx 
     if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
         p.t_ksk > 64)
         return set_error(nullptr, FBS_E_INVALID, "parameter out of range");
+    if (p.bsk_group > 2 || (p.bsk_group == 2 && (p.n & 1)))
+        return set_error(nullptr, FBS_E_INVALID, "bsk_group is 0, 1 or 2, and 2 needs an even n");
     ctx->N = 1u << p.log_n_poly;
     ctx->D = p.k * ctx->N;
     ctx->rows = (p.k + 1) * p.l_bsk;
+    ctx->group = p.bsk_group == 2 ? 2 : 1;
+    ctx->n_ggsw = ctx->group == 2 ? (size_t)p.n / 2 * 3 : p.n;
     ctx->ksk_stride = ((p.n + 1 + 255) / 256) * 256;
     int rc = dev_supported(ctx.get());
     if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
@@ -188,7 +192,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_ms,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
@@ -223,7 +227,7 @@ int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]) {
     if (!ctx || !sizes) return FBS_E_INVALID;
     sizes[0] = ctx->p.n;
     sizes[1] = ctx->D;
-    sizes[2] = (size_t)ctx->p.n * ctx->rows * (ctx->p.k + 1) * ctx->N;
+    sizes[2] = ctx->n_ggsw * ctx->rows * (ctx->p.k + 1) * ctx->N;
     sizes[3] = (size_t)ctx->D * ctx->p.t_ksk * (ctx->p.n + 1);
     return FBS_OK;
 }

@@ -114,12 +114,19 @@ void host_keygen(fbs_ctx *ctx) {
         for (uint32_t i = 0; i < N; i++)
             if (ctx->sk_glwe[(size_t)c * N + i]) support[c].push_back(i);
 
+    // the bit GGSW sample g encrypts: key bit g, or for pairs (s0, s1) of key bits the products s0(1-s1), (1-s0)s1, s0 s1
+    auto ggsw_bit = [&](size_t g) -> uint64_t {
+        if (ctx->group != 2) return ctx->sk_lwe[g];
+        const uint64_t s0 = ctx->sk_lwe[2 * (g / 3)], s1 = ctx->sk_lwe[2 * (g / 3) + 1];
+        return g % 3 == 0 ? (s0 & (1 - s1)) : g % 3 == 1 ? ((1 - s0) & s1) : (s0 & s1);
+    };
     const size_t row_words = (size_t)(k + 1) * N;
-    ctx->bsk.assign((size_t)n * rows * row_words, 0);
-    parallel_for((size_t)n * rows, [&](size_t r0, size_t r1) {
+    ctx->bsk.assign(ctx->n_ggsw * rows * row_words, 0);
+    parallel_for(ctx->n_ggsw * rows, [&](size_t r0, size_t r1) {
         std::vector<uint64_t> prod(N);
         for (size_t r = r0; r < r1; r++) {
-            uint32_t i = (uint32_t)(r / rows), rr = (uint32_t)(r % rows), comp = rr / l, lv = rr % l;
+            size_t i = r / rows;
+            uint32_t rr = (uint32_t)(r % rows), comp = rr / l, lv = rr % l;
             uint64_t *row = ctx->bsk.data() + r * row_words;
             uint64_t *body = row + (size_t)k * N;
             for (uint32_t j = 0; j < N; j++)
@@ -136,7 +143,7 @@ void host_keygen(fbs_ctx *ctx) {
                 }
                 for (uint32_t j = 0; j < N; j++) body[j] = fq_add(body[j], prod[j]);
             }
-            if (ctx->sk_lwe[i]) row[(size_t)comp * N] = fq_add(row[(size_t)comp * N], ctx->g[lv]);
+            if (ggsw_bit(i)) row[(size_t)comp * N] = fq_add(row[(size_t)comp * N], ctx->g[lv]);
         }
     });
 

@@ -60,6 +60,8 @@ struct fbs_ctx {
     uint64_t seed = 0;
     int device = 0;
     uint32_t N = 0, D = 0, rows = 0;   // D = k*N, rows = (k+1)*l
+    uint32_t group = 1;                // key bits per blind-rotation step (1 or 2)
+    size_t n_ggsw = 0;                 // GGSW samples in the bootstrapping key: n, or 3n/2 for group 2
     uint32_t ksk_stride = 0;           // padded n+1
     uint64_t delta_half = 0;
     uint64_t g[16]{};                  // round(q / B^(lv+1))
@@ -79,6 +81,7 @@ struct fbs_ctx {
     uint64_t *d_ks_corr = nullptr;   // [ksk_stride]  (B/2) * sum of all key-switching-key rows: balanced digits from unsigned fields
     uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
     uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)
+    uint64_t *d_psi_pow = nullptr;    // [N] psi^x, centred doubles: what the transforms of the monomials X^e - 1 are made from (group 2)
     uint32_t *d_ms = nullptr;        // scratch: mod-switched small ciphertexts [capacity][n+1]
     size_t ms_capacity = 0;
     uint32_t *d_idx = nullptr;       // scratch for index arrays of the host-index wires API

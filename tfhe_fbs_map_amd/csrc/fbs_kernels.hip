@@ -406,6 +406,8 @@ int dev_supported(const fbs_ctx *ctx) {
     if (p.t_ksk < 1 || p.gamma_ksk < 1 || p.t_ksk * p.gamma_ksk > 31 || p.t_ksk * p.gamma_ksk > FQ_BITS - 2)
         return set_error(ctx, FBS_E_INVALID, "need 1 <= t*gamma <= 31");
     if (p.n < 1 || p.n > 4096) return set_error(ctx, FBS_E_INVALID, "need 1 <= n <= 4096");
+    if (p.bsk_group == 2 && (p.log_n_poly < 10 || p.l_bsk > 5))
+        return set_error(ctx, FBS_E_INVALID, "two key bits per step (bsk_group = 2) is built for N = 1024 and 2048, l <= 5");
     // lazy FP64 ranges (fbs_field.hpp): partial external products stay below 2^50 while (k+1)*l <= 20
     if ((p.k + 1) * p.l_bsk > 20) return set_error(ctx, FBS_E_INVALID, "need (k+1)*l <= 20");
     // 64-bit key-switch accumulators: D*t digits < 2^gamma times words < 2^46

@@ -33,6 +33,12 @@ struct SplitNtt {
     __device__ static __forceinline__ void sync() { Base::sync(); }
     __host__ __device__ static constexpr uint32_t key_word(uint32_t t, int m) { return Base::key_word(t, m); }
     static constexpr int LANE_TABLE_OFFSET = 0;
+    // Where the evaluation held in register m of lane t after forward() sits in the output ARRAY of the textbook in-place
+    // Cooley-Tukey transform (position P holds the value at psi^(2 bitrev(P) + 1)): half h = m / 8 is array half h, and
+    // the last group's layout is local index 8 t + r.  Lane and register contribute disjoint bits.
+    static constexpr bool HAS_EVAL_POSITION = true;
+    __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return t << 3; }
+    __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (N / 2) + (uint32_t)(m & 7); }
     __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (uint32_t)m * LANES + t; }
     // input / output layout of the coefficient domain: register m of lane t = coefficient t + LANES * m
     template <int G>
@@ -268,6 +274,10 @@ struct PairNtt {
     using Half = SplitNtt<LOGN - 1, 6>;
     static_assert(E == 16 && Half::E == 16, "two waves, 16 coefficients per lane");
     static constexpr int LANE_TABLE_OFFSET = N;   // where the per-lane table starts inside the uploaded twiddle buffer
+    // array position of the evaluation in register m of thread t (see SplitNtt): wave w holds array half w
+    static constexpr bool HAS_EVAL_POSITION = true;
+    __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return (t >> 6) * (uint32_t)M + ((t & 63u) << 3); }
+    __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (M / 2) + (uint32_t)(m & 7); }
     __device__ static __forceinline__ Twiddles half_table(const Twiddles &tw, uint32_t w) {
         Twiddles sub = tw;
         sub.lane = tw.lane + w * (uint32_t)M;

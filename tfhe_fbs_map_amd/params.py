@@ -83,7 +83,14 @@ def variances(prm: Params):
     # rounding of the decomposition (half an ulp of q/B^l) seen through a binary GLWE key -- the latter only in the
     # steps whose LWE key bit is 1 (the CMUX output is s_i times the rounded difference): half of them.
     # Measured on the GPU this lands 15-35 % above the observed noise (tests/test_gpu_parity.py).
-    v_br = n * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + 0.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
+    if prm.bsk_group == 2:
+        # two key bits per step: n/2 external products by a bundle of three keys, each times a monomial difference
+        # X^e - 1 (squared norm 2): 6 sigma^2 of key noise per product where two single steps carry 2; the rounding of
+        # the decomposition of ACC is seen through X^(a0 s0 + a1 s1) - 1, non-zero for three of the four key-bit pairs
+        v_br = n / 2.0 * ((k + 1) * l * N * (B * B + 2) / 12.0 * 6.0 * s_glwe ** 2
+                          + 1.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
+    else:
+        v_br = n * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + 0.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
     # key switch: kN t balanced digits in [-2^g/2, 2^g/2) against key noise, plus the rounding to t*gamma bits
     # seen through a binary key
     v_ks = k * N * (t * (b2 * b2 + 2) / 12.0 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
@@ -116,7 +123,10 @@ def bootstrap_cost(prm: Params) -> float:
     def blind(n_, l_, N_, log_n):
         return n_ * ((k + 1) * (l_ + 1) * N_ * log_n / 2.0 * 8.0 + (k + 1) ** 2 * l_ * N_ * 7.0)
 
-    return 0.95 * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.05 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
+    # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.81 with one
+    # gadget level (11.4 against 14.1 ms at n = 718, N = 2048); with more levels the kernel runs out of registers (2.2)
+    pairs = 1.0 if prm.bsk_group != 2 else (0.81 if l == 1 else 2.2)
+    return 0.95 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.05 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
 # ---- selector ------------------------------------------------------------------------------------------------------
@@ -133,7 +143,7 @@ def _switch_fits(t, g, N):
 
 def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security: int | None = 128,
                   sigma: int | None = None, poly_sizes=(9, 10, 11), n_range=(450, 1200, 4),
-                  floor_margin: float | None = None) -> Params:
+                  floor_margin: float | None = None, groups=(1, 2)) -> Params:
     """Cheapest parameter set (n, N, l, beta, t, gamma and both noises) for plaintext modulus p and squared 2-norm
     `norm2` whose modelled margin is at least `min_margin` standard deviations -- what the reference obtains from its
     patched optimizer for (precision, sq_norm2) (experiments/add_exec_estimates.py:9-16, concrete.patch:21-27,163).
@@ -141,7 +151,9 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     security = 128: each noise is the smallest the security line allows for its dimension (`sigma_min`); n runs over
     `n_range`, N over 2^poly_sizes (k = 1: the kernels' shape), the gadget over 1..6 levels of 3..23 bits, the key
     switch over 1..23 levels of 1..6 bits.  security = None with `sigma`: the same search at a fixed noise (the
-    reduced-noise benchmark setting).  Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
+    reduced-noise benchmark setting).  `groups`: key bits per blind-rotation step to consider (2 = the multi-bit form: half
+    the steps on bundles of three GGSW samples, 1.5x the key, more noise per step; built for N >= 1024, l <= 5, even n).
+    Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
     (p too large for N <= 2048 at this security level); with `floor_margin` the requirement is first relaxed in steps of
     half a sigma down to that floor (p = 31 at norm2 = 325 tops out just under 6 sigma: the modulus switch at
     N = 2048 alone leaves 5.9)."""
@@ -150,7 +162,7 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
         m = min_margin
         while True:
             try:
-                return choose_params(p, norm2, m, security, sigma, poly_sizes, n_range)
+                return choose_params(p, norm2, m, security, sigma, poly_sizes, n_range, None, groups)
             except ValueError:
                 if m <= floor_margin:
                     raise
@@ -170,9 +182,13 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
         v_ms = (1 + ns / 2.0) / (12.0 * (2.0 * N) ** 2)
         if (v_ms >= need).all():
             continue
-        for l, beta in _GADGETS:
+        for (l, beta), group in [((l_, b_), g_) for (l_, b_) in _GADGETS for g_ in groups]:
+            if group == 2 and (log_n < 10 or l > 5):
+                continue
             B = 2.0 ** beta
-            v_br = ns * ((k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2 + 0.5 * (1 + k * N / 2.0) / (12.0 * B ** (2 * l)))
+            key_term = (k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2
+            round_term = (1 + k * N / 2.0) / (12.0 * B ** (2 * l))
+            v_br = ns * (key_term + 0.5 * round_term) if group == 1 else ns / 2.0 * (6.0 * key_term + 1.5 * round_term)
             room = need - v_ms - norm2 * v_br
             if (room <= 0).all():
                 continue
@@ -186,7 +202,7 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
                     continue
                 n = int(ns[ok[0]])                          # cost grows with n: the smallest feasible n is the cheapest
                 cand = Params(n=n, log_n_poly=log_n, k=k, l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=g, p_msg=p,
-                              sigma_lwe=int(round(s_lwe[ok[0]] * q)), sigma_glwe=int(round(s_glwe * q)))
+                              sigma_lwe=int(round(s_lwe[ok[0]] * q)), sigma_glwe=int(round(s_glwe * q)), bsk_group=group)
                 key = (bootstrap_cost(cand), n, l, t)
                 if best is None or key < best[0]:
                     best = (key, cand)
