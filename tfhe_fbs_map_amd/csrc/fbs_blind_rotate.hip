@@ -307,14 +307,18 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     constexpr int FIRST = DIG == 3 ? 2 : 0;
     constexpr bool ONE_LEVEL = DIG == 4;
     // [component][exchange buffer | twiddle table][N], then psi^x for x < N (psi^(x+N) = -psi^x): 5 N words = 40 KB at
-    // N = 1024, 80 KB at N = 2048 -- exactly what lets 8 waves share a CU's 160 KB
-    __shared__ double lds_all[2 * 2 * N + N];
+    // N = 1024, 80 KB at N = 2048 -- exactly what lets 8 waves share a CU's 160 KB.  The psi table is stored TRANSPOSED,
+    // word (x mod G) * N/G + x / G with G = 2^EVAL_GROUP_LOG2: the exponents a wave gathers for one register are G * (e *
+    // lane permutation) + uniform, an arithmetic progression of stride G e -- in natural order all 64 lanes of an odd e would
+    // fall on 4 of the 32 bank pairs (measured: 2.75e9 conflict cycles per launch, the LDS pipe 66 % busy); transposed they
+    // walk the banks with stride e (two-way for odd e, which a 64-lane 8-byte read is anyway; at worst eight-way).
+    __shared__ __attribute__((aligned(16384))) double lds_all[2 * 2 * N + N];
+    constexpr int GLOG = W::EVAL_GROUP_LOG2, G = 1 << GLOG;
     const uint32_t comp = (threadIdx.x >> LL) & 1u;
     const uint32_t t = threadIdx.x & (LANES - 1);
     double *lds = lds_all;
     double *mine = lds + comp * 2 * N;
     double *theirs = lds + (comp ^ 1u) * 2 * N;
-    const char *psi = reinterpret_cast<const char *>(lds + 4 * N);
     typename W::Xchg xc{mine, 0};
     Twiddles twf(a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_fwd), twi(a.tw_inv + W::LANE_TABLE_OFFSET, a.tw_inv);
     static_assert(LL <= FBS_ONE_BUFFER_MAX_LL, "one exchange buffer per polynomial, twiddle tables beside it");
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
         for (int m = 0; m < E / 2; m++) {   // the two components' threads copy half of the psi table each
             const uint32_t x = comp * (N / 2) + t + (uint32_t)LANES * m;
-            lds[4 * N + x] = a.psi_pow[x];
+            lds[4 * N + (x & (G - 1)) * (N / G) + (x >> GLOG)] = a.psi_pow[x];
         }
         __syncthreads();
         twf.lane = lds + N;
@@ -363,11 +367,15 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         round_offset += (double)(bhalf << (j * a.beta));
         sign_bits |= bhalf << (j * a.beta);
     }
-    // zeta^e for the evaluation point zeta = psi^o a register holds: exponent e * o mod 2N, o = o_lane + c_m with
-    // o_lane = 2 bitrev(lane part of the array position) + 1 and c_m = 2 bitrev(register part), a compile-time constant.
-    // Kept times 8: bits [3, 3 + LOGN) are the byte offset into the table of psi^x, x < N, bit 3 + LOGN the sign.
-    const uint32_t o_lane8 = (2u * (__builtin_bitreverse32(W::eval_position_lane(t)) >> (32 - LOGN)) + 1u) << 3;
-    constexpr uint32_t MASK8 = (uint32_t)(N - 1) << 3;
+    // zeta^e for the evaluation point zeta = psi^o a register holds: exponent x = e * o mod 2N, o = o_lane + c_m with
+    // o_lane = 2 bitrev(lane part of the array position) + 1 = G k_lane + r_lane (r_lane wave-uniform) and c_m = 2 bitrev(
+    // register part), a compile-time constant.  x = G a + b with b wave-uniform; table word b N/G + (a mod N/G), sign = bit
+    // log2(N/G) of a.  Everything but e * k_lane is scalar arithmetic.
+    const uint32_t o_lane = 2u * (__builtin_bitreverse32(W::eval_position_lane(t)) >> (32 - LOGN)) + 1u;
+    const uint32_t k_lane8 = (o_lane >> GLOG) << 3;
+    const uint32_t r_lane = __builtin_amdgcn_readfirstlane(o_lane & (G - 1));
+    constexpr uint32_t MASK8 = (uint32_t)(N / G - 1) << 3;
+    const uint32_t psi_base = (uint32_t)(uintptr_t)(lds + 4 * N);   // LDS byte address of the table (16 KB aligned)
 
     const uint32_t n_pairs = a.n / 2;
     uint32_t e0_next = ms[0], e1_next = ms[1];
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
         uint32_t lane8[3];
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) lane8[jj] = __umul24(e[jj], o_lane8);
+        for (int jj = 0; jj < 3; jj++) lane8[jj] = __umul24(e[jj], k_lane8);
 
         // ---- ACC_c itself, rounded to the closest multiple of q / B^l; packed balanced digits -------------
         uint32_t digits[E];
@@ -426,11 +434,16 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
                 for (int jj = 0; jj < 3; jj++)
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const uint32_t creg8 = (2u * (__builtin_bitreverse32(W::eval_position_reg(2 * j + u)) >> (32 - LOGN))) << 3;
-                        const uint32_t off = lane8[jj] + e_lv[jj] * creg8;
-                        const double v = *reinterpret_cast<const double *>(psi + (off & MASK8));
+                        const uint32_t c_m = 2u * (__builtin_bitreverse32(W::eval_position_reg(2 * j + u)) >> (32 - LOGN));
+                        const uint32_t rsum = r_lane + (c_m & (G - 1));                       // uniform from here ...
+                        const uint32_t ku = (c_m >> GLOG) + (rsum >> GLOG), ru = rsum & (G - 1);
+                        const uint32_t eru = e_lv[jj] * ru;
+                        const uint32_t u8 = (e_lv[jj] * ku + (eru >> GLOG)) << 3;
+                        const uint32_t sbase = psi_base + (eru & (G - 1)) * (uint32_t)(N / G * 8);    // ... to here
+                        const uint32_t t8 = lane8[jj] + u8;
+                        const double v = *reinterpret_cast<const __attribute__((address_space(3))) double *>((t8 & MASK8) | sbase);
                         // (+-) by the bit above the table index, then - 1
-                        const int hi = __double2hiint(v) ^ (int)((off << (31 - 3 - LOGN)) & 0x80000000u);
+                        const int hi = __double2hiint(v) ^ (int)((t8 << (31 - 3 - (LOGN - GLOG))) & 0x80000000u);
                         mono[jj][u] = __hiloint2double(hi, __double2loint(v)) - 1.0;
                     }
                 // key words of the bundle: lazy sums of three exact products (< 2.3 q).  With |x| < 2^49.3 (general first

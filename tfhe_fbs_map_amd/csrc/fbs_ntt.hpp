@@ -246,7 +246,8 @@ struct PolyNtt {
     }
 
     static constexpr int LANE_TABLE_OFFSET = 0;   // per-lane twiddle gathers read the uploaded table from its start
-    static constexpr bool HAS_EVAL_POSITION = false;   // which evaluation point a register holds is not published for this shape
+    static constexpr bool HAS_EVAL_POSITION = false;
+    static constexpr int EVAL_GROUP_LOG2 = 0;   // which evaluation point a register holds is not published for this shape
     __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t) { return 0; }
     __host__ __device__ static constexpr uint32_t eval_position_reg(int) { return 0; }
     // word (of the partner's exchange buffer) where thread t parks register m of a polynomial handed over between components

@@ -37,6 +37,9 @@ struct SplitNtt {
     // Cooley-Tukey transform (position P holds the value at psi^(2 bitrev(P) + 1)): half h = m / 8 is array half h, and
     // the last group's layout is local index 8 t + r.  Lane and register contribute disjoint bits.
     static constexpr bool HAS_EVAL_POSITION = true;
+    // the exponents 2 bitrev(P) + 1 of the points a wave holds in one register are 2^EVAL_GROUP_LOG2 * (a permutation of the
+    // lanes) + a wave-uniform remainder
+    static constexpr int EVAL_GROUP_LOG2 = 2;
     __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return t << 3; }
     __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (N / 2) + (uint32_t)(m & 7); }
     __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (uint32_t)m * LANES + t; }
@@ -276,6 +279,7 @@ struct PairNtt {
     static constexpr int LANE_TABLE_OFFSET = N;   // where the per-lane table starts inside the uploaded twiddle buffer
     // array position of the evaluation in register m of thread t (see SplitNtt): wave w holds array half w
     static constexpr bool HAS_EVAL_POSITION = true;
+    static constexpr int EVAL_GROUP_LOG2 = 3;
     __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return (t >> 6) * (uint32_t)M + ((t & 63u) << 3); }
     __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (M / 2) + (uint32_t)(m & 7); }
     __device__ static __forceinline__ Twiddles half_table(const Twiddles &tw, uint32_t w) {

@@ -123,9 +123,11 @@ def bootstrap_cost(prm: Params) -> float:
     def blind(n_, l_, N_, log_n):
         return n_ * ((k + 1) * (l_ + 1) * N_ * log_n / 2.0 * 8.0 + (k + 1) ** 2 * l_ * N_ * 7.0)
 
-    # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.81 with one
-    # gadget level (11.4 against 14.1 ms at n = 718, N = 2048); with more levels the kernel runs out of registers (2.2)
-    pairs = 1.0 if prm.bsk_group != 2 else (0.81 if l == 1 else 2.2)
+    # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.72 with one
+    # gadget level (10.2 against 14.1 ms per 1024 bootstraps at N = 2048, n = 722 / 718).  With l levels the bundle costs
+    # 6 l exact products per coefficient and pair of key bits where it saves l + 1 transforms: it does not pay beyond
+    # l = 1 (P1024, l = 3: 13.5 against 10.8 ms)
+    pairs = 1.0 if prm.bsk_group != 2 else (0.72 if l == 1 else 1.25)
     return 0.95 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.05 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
