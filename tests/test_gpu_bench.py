@@ -1,0 +1,48 @@
+"""bench.py is what the driver runs: its JSON line must keep the contract fields, and the circuit workload must agree with
+the library it drives.  Small sizes here; the real sizes are the driver's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    lines = [ln for ln in rc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_fields():
+    d = run_bench("--steps", "3", "--warmup", "1", "--batch", "256", "--cpu-sample", "8")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "secure"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "FBS/s" and d["vs_baseline"] is None and d["decrypt_ok"]
+    assert abs(d["value"] - 256 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "fp64_valu" and r["kernel"].startswith("k_blind_rotate<10,") and r["avg_launch_ms"] > 0
+    assert 0 < r["hbm_algorithmic_frac"] and "whole_path_frac" not in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["bit_exact_vs_gpu"] and c["cores"] >= 1 and c["cpu_model"] and c["one_thread"]["value"] > 0
+    p = d["config"]["params"]
+    assert p["sigma_lwe"] == 64 and p["security_bits_estimate"] < 60          # the headline says what it is
+    s = d["secure"]
+    assert s["decrypt_ok"] and s["params"]["security_bits_estimate"] >= 127.9 and s["margin_sigmas_at_norm2_70"] >= 6.0
+    assert s["n1024_p4"]["decrypt_ok"] and s["n1024_p4"]["params"]["N"] == 1024
+
+
+@pytest.mark.parametrize("mode", ["gate", "sample"])
+def test_circuit_workload(mode):
+    d = run_bench("--workload", "circuit", "--mode", mode, "--circuit", "adder8__search_p15", "--samples", "8",
+                  "--steps", "1", "--warmup", "1")
+    assert d["decrypt_ok"] and d["config"]["mode"] == mode and d["config"]["rccl_ranks"] == 1
+    assert d["scaling"] == ("strong" if mode == "gate" else "weak")
+    assert d["config"]["wire_slots"] < d["config"]["wires"]
+    assert d["value"] > 0 and set(d["kernels_ms_per_step"]) == {"keyswitch", "blind_rotate", "lincomb"}

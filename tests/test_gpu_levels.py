@@ -159,3 +159,26 @@ def test_runners_on_rccl_equal_program_eval(nat, toy_params, one_rank_nccl, name
     for k, name_ in enumerate(low["out_names"]):
         if not const[k]:
             assert np.array_equal(ctx.decrypt(got[k]), expect[name_])
+
+
+def test_samples_are_chunked_when_the_wire_slots_do_not_fit(nat, toy_params, monkeypatch):
+    """fbs_eval / fbs_eval_dev evaluate the samples in chunks when the wire buffer would not fit in HBM.  With the budget
+    capped (test hook FBS_WIRE_BUDGET_MB) 37 samples run as several ragged chunks and must equal the one-chunk result."""
+    import torch
+    T = 37
+    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, "adder8__search_p7", T)
+    ref = prog.eval(cts, T)
+    monkeypatch.setenv("FBS_WIRE_BUDGET_MB", "2")               # 2 MB * 0.6 / (slots * 8200 B): a handful of samples
+    per_sample = prog.n_slots * prm.ct_words * 8
+    assert 2 * 2**20 * 0.6 / per_sample < T / 3
+    ctx2 = nat.Context(prm, seed=6)                              # a fresh context: its wire buffer has not grown yet
+    prog2 = nat.Program(ctx2, ctx2.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                        low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    assert np.array_equal(prog2.eval(cts, T), ref)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_out = torch.empty((prog2.n_outputs, T, prm.ct_words), dtype=torch.int64, device="cuda")
+    prog2.eval_dev(d_in.data_ptr(), T, d_out.data_ptr())
+    ctx2.sync()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ref)
+    for k, name in enumerate(low["out_names"]):
+        assert np.array_equal(ctx2.decrypt(ref[k]), expect[name])

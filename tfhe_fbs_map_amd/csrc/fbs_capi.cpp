@@ -2,6 +2,7 @@
 // program executor that stands behind `LutExecEnv.eval` (reference fbs_mapper/fbs_exec_env.py:208-229).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -771,7 +772,9 @@ static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *c
     const size_t per_sample = (size_t)prog->n_slots * ctw * 8 + (size_t)std::max(1u, prog->max_sources) * (ctx->p.n + 1) * 4;
     size_t free_b = 0, total_b = 0;
     FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    const size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4;
+    size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4;
+    // test hook: FBS_WIRE_BUDGET_MB caps what the wire slots may take, so that the chunked path runs at small sizes
+    if (const char *cap = getenv("FBS_WIRE_BUDGET_MB")) have = std::min<size_t>(have, (size_t)std::max(1, atoi(cap)) << 20);
     const size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / per_sample));
     const size_t words = Tc * (size_t)prog->n_slots * ctw;
     if (ctx->wires_capacity < words) {
