@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests.helpers import load_fixture, subsample
-from tfhe_fbs_map_amd import Context, ExecConfig, Params, parse_fbs, _native as nat
+from tfhe_fbs_map_amd import P1024, Context, parse_fbs, _native as nat
 
 for name, T in (("mul16__search_p15", 1000), ("adder128__search_p15", 1000), ("trivium_stream_short128__search_p15", 1000),
                 ("trivium_stream_v2__search_p15", 64)):
@@ -11,12 +11,13 @@ for name, T in (("mul16__search_p15", 1000), ("adder128__search_p15", 1000), ("t
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     low = env.lower()
     ins, expect = subsample(rec, T)
-    if os.environ.get("AUTO_PARAMS"):          # params.choose_params at the program's (p, norm2) instead of P1024
+    if os.environ.get("SECURE"):               # the 128-bit set of params.choose_params at the program's (p, norm2)
         from tfhe_fbs_map_amd import choose_params
         prm = choose_params(15, env.stats()["norm2_linprod"])
-        print("  chosen: l=%d beta=%d t=%d gamma=%d" % (prm.l_bsk, prm.beta_bsk, prm.t_ksk, prm.gamma_ksk))
+        print("  chosen: n=%d N=%d l=%d beta=%d t=%d gamma=%d, %d key bit(s) per step" % (
+            prm.n, prm.N, prm.l_bsk, prm.beta_bsk, prm.t_ksk, prm.gamma_ksk, prm.bsk_group))
     else:
-        prm = Params()
+        prm = P1024
     ctx = Context(prm, seed=1)
     tv = ctx.tvset(low["tables"])
     prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],

@@ -3,13 +3,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests.helpers import load_fixture, subsample
-from tfhe_fbs_map_amd import Context, Params, parse_fbs, _native as nat
+from tfhe_fbs_map_amd import P1024, Context, parse_fbs, _native as nat
 from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend, SampleShardedRunner
 
 rec = load_fixture("mul16__search_p15"); T = 200
 env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]); low = env.lower()
 ins, expect = subsample(rec, T)
-ctx = Context(Params(), seed=1); tv = ctx.tvset(low["tables"])
+ctx = Context(P1024, seed=1); tv = ctx.tvset(low["tables"])
 prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
                    low["term_coef"], low["term_src"], low["out_wire"])
 cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]))
@@ -18,7 +18,7 @@ t0 = time.time(); ref = prog.eval(cts, T); t_prog = time.time() - t0
 nf = prog.n_bootstrap * T
 print("fbs_eval            %.2fs  %.0f FBS/s" % (t_prog, nf / t_prog))
 for cls in (GateShardedRunner, SampleShardedRunner):
-    r = cls(low, GpuBackend(ctx, tv)); r.run(cts[:, :2].copy(), 2)
+    r = cls(GpuBackend(prog)); r.run(cts[:, :2].copy(), 2)
     t0 = time.time(); out = r.run(cts, T); torch.cuda.synchronize(); dt = time.time() - t0
     print("%-20s %.2fs  %.0f FBS/s  identical=%s" % (cls.__name__, dt, nf / dt, np.array_equal(out, ref)))
 # host-buffer flat batch (PCIe inclusive)
