@@ -236,7 +236,8 @@ def test_lincomb_kernel_matches_oracle(nat, toy_pair):
 
 @pytest.mark.parametrize("name,T", [("demo_fbs_exec_env", 2), ("edge_outputs", 5), ("edge_nomerge", 5),
                                     ("full_adder__search_p7", 6), ("adder8__search_p7", 3),
-                                    ("aes_sbox__search_p7", 2), ("mul4__naive_p7", 2)])
+                                    ("aes_sbox__search_p7", 2), ("mul4__naive_p7", 2),
+                                    ("mul16__search_p15", 2)])          # BASELINE config 3's program, every ciphertext
 def test_program_ciphertexts_bit_exact(nat, toy_params, name, T):
     """Whole program on the GPU executor (fbs_eval: level-batched lincomb + bootstrap kernels) vs the oracle
     evaluating the same instruction list one ciphertext at a time: every output word identical."""
