@@ -221,6 +221,21 @@ const char *fbs_profile_kernel(const fbs_ctx *ctx, int which);
 /* block until all work queued on the context's stream (or `stream`) has finished */
 int fbs_sync(fbs_ctx *ctx, void *stream);
 
+/* ---- mapper: coefficient search ------------------------------------
+ * Stands behind MapToFBSHeur._find_lincomb_coefs_search (fbs_mapper/map_to_fbs.py:363-392): x, y are the multi-value
+ * columns of two cones over the `rows` rows of their joint truth table (xy_mvt[:, 0], xy_mvt[:, 1]), tt the merged output
+ * bit per row (r_tt).  On success *found says whether a legal (a, b) exists; then ab = {a, b} and, if mvt != NULL,
+ * mvt[r] = a x[r] + b y[r] -- the reference's (r_ab, r_mvt), chosen by the reference's rule among the reference's
+ * candidates.  Needs no keys: a searcher is bound to a device only.  max_fbs_size <= 128. */
+typedef struct fbs_searcher fbs_searcher;
+int fbs_searcher_create(int device, fbs_searcher **out);
+void fbs_searcher_destroy(fbs_searcher *s);
+const char *fbs_searcher_last_error(const fbs_searcher *s);
+/* device time of the most recent search kernel (HIP events on the searcher's stream), ms */
+double fbs_searcher_last_kernel_ms(const fbs_searcher *s);
+int fbs_search_lincomb_coefs(fbs_searcher *s, const int32_t *x, const int32_t *y, const uint8_t *tt, uint32_t rows,
+                             uint32_t fbs_size, uint32_t max_fbs_size, int32_t ab[2], int64_t *mvt, int *found);
+
 /* ---- debug hook: negacyclic product of two polynomials on the device NTT ---- */
 int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c);
 

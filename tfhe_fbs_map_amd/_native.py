@@ -159,6 +159,11 @@ def _load():
         "fbs_profile_kernel": (C.c_char_p, [vp, i32]),
         "fbs_sync": (i32, [vp, vp]),
         "fbs_debug_polymul": (i32, [vp, vp, vp, vp]),
+        "fbs_searcher_create": (i32, [i32, C.POINTER(vp)]),
+        "fbs_searcher_destroy": (None, [vp]),
+        "fbs_searcher_last_error": (C.c_char_p, [vp]),
+        "fbs_searcher_last_kernel_ms": (C.c_double, [vp]),
+        "fbs_search_lincomb_coefs": (i32, [vp, vp, vp, vp, u32, u32, u32, vp, vp, C.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = the library does not match the header
@@ -172,7 +177,8 @@ EXPORTED_SYMBOLS = (
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
     "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_destroy", "fbs_program_info",
-    "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
+    "fbs_searcher_create", "fbs_searcher_destroy", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms",
+    "fbs_search_lincomb_coefs", "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
     "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
 )
 
