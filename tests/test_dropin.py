@@ -50,3 +50,39 @@ s = io.StringIO(); lut.print(os=s, show_outputs=True); sys.stdout.write(s.getval
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
                          env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1")).stdout
     assert out == load_fixture(fixture)["fbs"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("p,fixture", [(7, "full_adder__search_p7"), (15, "aes_sbox__search_p15")])
+def test_reference_mapper_with_the_search_swapped_in(p, fixture):
+    """`mapper_search.install(MapToFBSHeur)` on the REFERENCE's own class: the mapper must walk through the replaced
+    method and map to the same program.  There is no GPU in the build container, so here the function behind the
+    binding is stood in for by the test oracle (same arguments, same return value); on the GPU box
+    tests/test_mapper_search.py holds the kernel itself against the recorded reference results."""
+    circuit = fixture.split("__")[0]
+    gen = {"full_adder": "full_adder_bench", "aes_sbox": "aes_sbox"}[circuit]
+    code = f"""
+import sys, io, logging
+sys.dont_write_bytecode = True
+sys.argv = ['x']
+sys.path.insert(0, '/root/reference'); sys.path.insert(0, '/root/reference/experiments'); sys.path.insert(0, {REF!r})
+sys.path.insert(0, {ROOT!r})
+import bit_exec_env, map_to_fbs, generate_benchmarks as gb
+from tfhe_fbs_map_amd import mapper_search
+from oracle import mapper_search_oracle as mso
+calls = []
+def stand_in(xy_mvt, r_tt, fbs_size, max_fbs_size, device=0):
+    calls.append(len(r_tt))
+    return mso.find_lincomb_coefs_search(xy_mvt[:, 0], xy_mvt[:, 1], r_tt, fbs_size, max_fbs_size)
+mapper_search.find_lincomb_coefs_search = stand_in
+mapper_search.install(map_to_fbs.MapToFBSHeur)
+logging.disable(logging.CRITICAL)
+env = bit_exec_env.BitExecEnv(); gb.Bit.set_env(env); gb.{gen}(); env.remove_dangling_nodes()
+m = map_to_fbs.MapToFBSHeur(fbs_size={p}, max_fbs_size={2 * p}, max_truth_table_size=16, cone_merger='search')
+lut = m.map(env); lut.remove_dangling_nodes()
+assert calls, 'the replaced method was never reached'
+s = io.StringIO(); lut.print(os=s, show_outputs=True); sys.stdout.write(s.getvalue())
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1")).stdout
+    assert out == load_fixture(fixture)["fbs"]
