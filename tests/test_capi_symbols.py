@@ -61,9 +61,9 @@ def test_non_power_of_two_polynomial_size_is_refused_with_its_own_code():
             Params.for_poly_size(n_poly)
         assert e.value.code == -5 and "not a power of two" in str(e.value)
     with pytest.raises(FbsError) as e:
-        Params.for_poly_size(4096)
+        Params.for_poly_size(8192)
     assert e.value.code == -1
-    assert Params.for_poly_size(2048, p_msg=31).log_n_poly == 11
+    assert Params.for_poly_size(2048, p_msg=31).log_n_poly == 11 and Params.for_poly_size(4096).log_n_poly == 12
 
 
 def test_product_never_imports_the_oracle():

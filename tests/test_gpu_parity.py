@@ -42,7 +42,7 @@ def test_device_is_gfx950(toy_pair):
     assert toy_pair[0].device_info.startswith("gfx950")
 
 
-@pytest.mark.parametrize("log_n", [8, 9, 10, 11])
+@pytest.mark.parametrize("log_n", [8, 9, 10, 11, 12])
 def test_device_ntt_product(nat, toy_params, log_n):
     ctx = nat.Context(toy_params.replace(log_n_poly=log_n, n=2), seed=2)
     rng = np.random.default_rng(log_n)
@@ -68,7 +68,7 @@ def test_keys_and_encryption_identical_to_oracle(toy_pair, p1024_pair):
         assert np.array_equal(ctx.decrypt(o.encrypt(msgs, 5)), msgs)
 
 
-@pytest.mark.parametrize("log_n", [8, 9, 10, 11])
+@pytest.mark.parametrize("log_n", [8, 9, 10, 11, 12])
 def test_bootstrap_bit_exact_all_sizes(nat, toy_params, log_n):
     prm = toy_params.replace(log_n_poly=log_n)
     ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
@@ -333,7 +333,7 @@ def test_noise_model_holds_for_the_secure_set(nat):
     assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)
 
 
-@pytest.mark.parametrize("log_n", [10, 11])
+@pytest.mark.parametrize("log_n", [10, 11, 12])
 @pytest.mark.parametrize("l,beta", [(1, 20), (1, 8), (3, 7), (2, 10), (5, 5)])
 def test_two_key_bits_per_step_bit_exact(nat, toy_params, log_n, l, beta):
     """bsk_group = 2 (k_blind_rotate_pairs: the bundle of three GGSW samples per pair of key bits, built in the NTT
@@ -385,3 +385,18 @@ def test_noise_model_holds_with_two_key_bits_per_step(nat):
     measured = float(np.sqrt(np.mean(err ** 2)))
     print("two bits per step: measured %.3g predicted %.3g" % (measured, predicted))
     assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)
+
+
+@pytest.mark.parametrize("l,beta,t,gamma", [(1, 22, 8, 2), (2, 13, 16, 1), (3, 7, 5, 3), (6, 4, 8, 2)])
+def test_n4096_gadget_shapes_bit_exact(nat, toy_params, l, beta, t, gamma):
+    """N = 4096 (four waves per polynomial: two butterfly stages across the waves, then a wave-private transform each):
+    one-level, bounded and general kernel variants against the oracle."""
+    prm = toy_params.replace(log_n_poly=12, n=10, l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=gamma)
+    ctx, o = nat.Context(prm, seed=12), orc.Oracle(prm, seed=12)
+    msgs = np.concatenate([np.arange(len(tb)) for tb in MODES])
+    ids = np.concatenate([np.full(len(tb), i) for i, tb in enumerate(MODES)]).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=31)
+    got = ctx.bootstrap_batch(ctx.tvset(MODES), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, MODES, ids)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(tb) for tb in MODES]))

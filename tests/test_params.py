@@ -52,7 +52,7 @@ def test_selector_returns_secure_sets_with_the_asked_margin(p, norm2):
     assert margin_sigmas(c, norm2) >= 6.0
     assert c.sigma_lwe >= sigma_min(c.n) and c.sigma_glwe >= sigma_min(c.N) and security_bits(c) >= 127.9
     # the kernels can run it (dev_supported in csrc/fbs_kernels.hip)
-    assert 8 <= c.log_n_poly <= 11 and c.l_bsk * c.beta_bsk <= 30 and c.t_ksk * c.gamma_ksk <= 31
+    assert 8 <= c.log_n_poly <= 12 and c.l_bsk * c.beta_bsk <= 30 and c.t_ksk * c.gamma_ksk <= 31
     assert MODULUS_BITS + c.gamma_ksk + math.log2(c.t_ksk * c.N) <= 63.9
     # a looser error probability is never dearer; a larger norm never cheaper
     assert bootstrap_cost(choose_params(p, norm2, min_margin=REFERENCE_MARGIN)) <= bootstrap_cost(c) + 1e-9
@@ -63,12 +63,17 @@ def test_selector_moves_n_and_N():
     small, big = choose_params(2, 1), choose_params(15, 281)
     assert small.N == 1024 and big.N == 2048 and big.n > small.n
     assert choose_params(15, 281).n != choose_params(15, 281, min_margin=4.0).n
-    # p = 31 at norm2 = 325: the modulus switch at N = 2048 leaves 5.9 sigma, so 6 is out of reach ...
+    # p = 31 at norm2 = 325: the modulus switch at N = 2048 leaves 5.9 sigma, so 6 sigma takes N = 4096 ...
     with pytest.raises(ValueError):
-        choose_params(31, 325)
-    # ... and the executor's default relaxes towards the reference's own 4 sigma
-    c = choose_params(31, 325, floor_margin=REFERENCE_MARGIN)
+        choose_params(31, 325, poly_sizes=(9, 10, 11))
+    big = choose_params(31, 325)
+    assert big.N == 4096 and margin_sigmas(big, 325) >= 6.0 and security_bits(big) >= 127.9
+    # ... or a margin relaxed towards the reference's own 4 sigma at N = 2048, at half the cost
+    c = choose_params(31, 325, poly_sizes=(9, 10, 11), floor_margin=REFERENCE_MARGIN)
     assert c.N == 2048 and margin_sigmas(c, 325) >= 5.0 and security_bits(c) >= 127.9
+    assert bootstrap_cost(c) < 0.6 * bootstrap_cost(big)
+    with pytest.raises(ValueError):
+        choose_params(63, 100)                                   # beyond N = 4096
 
 
 def test_cost_ranking_against_the_references_points():

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-#define FBS_FOR_EACH_SHAPE(X) X(8) X(9) X(10) X(11)
+#define FBS_FOR_EACH_SHAPE(X) X(8) X(9) X(10) X(11) X(12)
 
 template <int LOGN>
 static int upload_keys_t(fbs_ctx *ctx) {
@@ -573,16 +573,16 @@ int dev_upload_keys(fbs_ctx *ctx) {
     const uint32_t N = ctx->N;
     std::vector<uint64_t> fwd, inv;
     host_twiddles(p.log_n_poly, fwd, inv);
-    std::vector<double> fwd_c(2 * (size_t)N), inv_c(2 * (size_t)N);   // the table and its two half-size subtrees (host_twiddles)
-    for (uint32_t i = 0; i < 2 * N; i++) {
+    std::vector<double> fwd_c(3 * (size_t)N), inv_c(3 * (size_t)N);   // the table, its two half-size and four quarter-size subtrees
+    for (uint32_t i = 0; i < 3 * N; i++) {
         fwd_c[i] = fq_centered(fwd[i]);
         inv_c[i] = fq_centered(inv[i]);
     }
     const size_t bsk_words = ctx->n_ggsw * ctx->rows * (p.k + 1) * N;
     const size_t ksk_rows = (size_t)ctx->D * p.t_ksk;
     if (!ctx->d_tw_fwd) {
-        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, 2 * (size_t)N * 8));
-        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, 2 * (size_t)N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_fwd, 3 * (size_t)N * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_tw_inv, 3 * (size_t)N * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_bsk_hat, bsk_words * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ksk, ksk_rows * ctx->ksk_stride * 8));
         FBS_HIP(ctx, hipMalloc(&ctx->d_ksk_f, ksk_rows * ctx->ksk_stride * 8));
@@ -672,7 +672,8 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         switch (p.log_n_poly) {
             PAIRS_FOR(10)
             PAIRS_FOR(11)
-            default: return set_error(ctx, FBS_E_INVALID, "two key bits per step: N = 1024 or 2048 only");
+            PAIRS_FOR(12)
+            default: return set_error(ctx, FBS_E_INVALID, "two key bits per step: N = 1024, 2048 or 4096 only");
         }
 #undef PAIRS_FOR
 #undef LAUNCH_PAIRS

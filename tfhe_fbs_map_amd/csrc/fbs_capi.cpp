@@ -125,10 +125,10 @@ int fbs_poly_size_check(uint32_t poly_size) {
         return set_error(nullptr, FBS_E_POLY_SIZE,
                          "N = " + std::to_string(poly_size) + " is not a power of two: X^N + 1 then has the factor X^" +
                              std::to_string(pow2) + " + 1, so a GLWE sample over it is no harder than one of degree " +
-                             std::to_string(pow2) + "; use a power-of-two N (256 .. 2048) and any plaintext modulus p");
+                             std::to_string(pow2) + "; use a power-of-two N (256 .. 4096) and any plaintext modulus p");
     }
-    if (poly_size < 256 || poly_size > 2048)
-        return set_error(nullptr, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048");
+    if (poly_size < 256 || poly_size > 4096)
+        return set_error(nullptr, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048, 4096");
     return FBS_OK;
 }
 

@@ -231,8 +231,8 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
 // twiddles for the merged negacyclic NTT: fwd[i] = psi^bitrev(i), inv[i] = psi^-bitrev(i), psi = 7^((q-1)/2N)
 // (any primitive 2N-th root gives the same ciphertexts: the transform is an internal representation).
 // Entries [N, 2N) repeat the two half-size subtrees (nodes 2 and 3 of the twiddle tree) as tables of their own, N/2
-// entries each: entry i of half h = entry ((2 + h) << d) + (i - 2^d), d = floor(log2 i) -- what the two-wave transform
-// (PairNtt, fbs_ntt_split.hpp) gathers from.
+// entries each: entry i of half h = entry ((2 + h) << d) + (i - 2^d), d = floor(log2 i); entries [2N, 3N) the four
+// quarter-size subtrees (nodes 4 .. 7) likewise -- what the multi-wave transforms (WavesNtt, fbs_ntt_split.hpp) gather from.
 // ---------------------------------------------------------------------------------------------
 void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv) {
     const uint32_t N = 1u << log_n;
@@ -246,15 +246,16 @@ void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint6
         fwd[i] = fq_pow(psi, r);
         inv[i] = fq_pow(psi_inv, r);
     }
-    fwd.resize(2 * (size_t)N, 1);
-    inv.resize(2 * (size_t)N, 1);
-    for (uint32_t h = 0; h < 2; h++)
-        for (uint32_t i = 1; i < N / 2; i++) {
-            uint32_t d = 31 - (uint32_t)__builtin_clz(i);
-            uint32_t big = ((2 + h) << d) + (i - (1u << d));
-            fwd[N + h * (N / 2) + i] = fwd[big];
-            inv[N + h * (N / 2) + i] = inv[big];
-        }
+    fwd.resize(3 * (size_t)N, 1);
+    inv.resize(3 * (size_t)N, 1);
+    for (uint32_t parts = 2, base = N; parts <= 4; parts *= 2, base += N)   // [N, 2N): the two halves; [2N, 3N): the four quarters
+        for (uint32_t h = 0; h < parts; h++)
+            for (uint32_t i = 1; i < N / parts; i++) {
+                uint32_t d = 31 - (uint32_t)__builtin_clz(i);
+                uint32_t big = ((parts + h) << d) + (i - (1u << d));
+                fwd[base + h * (N / parts) + i] = fwd[big];
+                inv[base + h * (N / parts) + i] = inv[big];
+            }
 }
 
 }  // namespace fbs

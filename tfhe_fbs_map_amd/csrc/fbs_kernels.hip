@@ -399,15 +399,15 @@ void prof_end(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t e0, hipEvent_t 
 int dev_supported(const fbs_ctx *ctx) {
     const fbs_params &p = ctx->p;
     if (p.k != 1) return set_error(ctx, FBS_E_INVALID, "this build supports GLWE dimension k = 1 only");
-    if (p.log_n_poly < 8 || p.log_n_poly > 11)
-        return set_error(ctx, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048");
+    if (p.log_n_poly < 8 || p.log_n_poly > 12)
+        return set_error(ctx, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048, 4096");
     if (p.l_bsk < 1 || p.beta_bsk < 1 || p.l_bsk * p.beta_bsk > 30 || p.l_bsk * p.beta_bsk > FQ_BITS - 2)
         return set_error(ctx, FBS_E_INVALID, "need 1 <= l*beta <= 30");
     if (p.t_ksk < 1 || p.gamma_ksk < 1 || p.t_ksk * p.gamma_ksk > 31 || p.t_ksk * p.gamma_ksk > FQ_BITS - 2)
         return set_error(ctx, FBS_E_INVALID, "need 1 <= t*gamma <= 31");
     if (p.n < 1 || p.n > 4096) return set_error(ctx, FBS_E_INVALID, "need 1 <= n <= 4096");
     if (p.bsk_group == 2 && (p.log_n_poly < 10 || p.l_bsk > 5))
-        return set_error(ctx, FBS_E_INVALID, "two key bits per step (bsk_group = 2) is built for N = 1024 and 2048, l <= 5");
+        return set_error(ctx, FBS_E_INVALID, "two key bits per step (bsk_group = 2) is built for N = 1024, 2048 and 4096, l <= 5");
     // lazy FP64 ranges (fbs_field.hpp): partial external products stay below 2^50 while (k+1)*l <= 20
     if ((p.k + 1) * p.l_bsk > 20) return set_error(ctx, FBS_E_INVALID, "need (k+1)*l <= 20");
     // 64-bit key-switch accumulators: D*t digits < 2^gamma times words < 2^46

@@ -35,7 +35,7 @@ struct Twiddles {
 // polynomials spread over up to 2^FBS_ONE_BUFFER_MAX_LL lanes exchange through ONE buffer (a second synchronisation
 // per exchange instead of a ping-pong pair), which leaves room for twiddle tables in LDS
 #ifndef FBS_ONE_BUFFER_MAX_LL
-#define FBS_ONE_BUFFER_MAX_LL 7
+#define FBS_ONE_BUFFER_MAX_LL 8
 #endif
 
 // First Cooley-Tukey butterfly of a forward transform, (a, b) <- (a + w b, a - w b), by what is known about the inputs:

@@ -250,36 +250,38 @@ struct SplitNtt {
     }
 };
 
-// Negacyclic NTT of one polynomial of size 2M held by TWO wavefronts (M = 1024: N = 2048), as one butterfly stage across
-// the pair plus one wave-private SplitNtt of size M per wave.
+// Negacyclic NTT of one polynomial of size N = W M held by W = 2^LOGW wavefronts (M = 1024: N = 2048 on two waves,
+// N = 4096 on four), as LOGW butterfly stages across the waves plus one wave-private SplitNtt of size M per wave.
 //
-// The first Cooley-Tukey stage (registers m and m+8 of the natural layout: register m of thread t = coefficient
-// t + 128 m) splits the polynomial into two independent size-M transforms hanging from nodes 2 and 3 of the twiddle tree.
-// Wave h takes half h: ONE trip through LDS re-deals the values (every thread writes its eight entries of each half,
-// wave h reads half h in SplitNtt's layout -- register m' of lane l = entry l + 64 m'), two workgroup barriers; everything
-// after that is wave-private (no barrier, the split schedule of SplitNtt hides its own LDS latency).  The generic
-// two-wave transform (PolyNtt<11,7>) needs four barriers per transform, spilled 35-54 registers inside the blind
-// rotation and conflicted in LDS; this one has the register budget of the N = 1024 kernel.
-// The inverse is the mirror image.  `bufs` of the exchange state is the polynomial's N-word LDS region; wave h uses
-// words [h M, (h+1) M) of it as its private SplitNtt buffer -- the very words only it reads in the re-deal, so no barrier is
-// needed between the re-deal and the private transform.
-// Twiddles: `uniform` is the table of the whole polynomial (N entries, tw[i] = psi^bitrev(i)); `lane` points at the two
-// halves' OWN tables back to back, M entries each: entry i of half h = entry ((2 + h) << d) + (i - 2^d) of the big table,
+// The first LOGW Cooley-Tukey stages pair registers of one thread (natural layout: register m of thread t = coefficient
+// t + 64 W m; stage s pairs m with m + 8 >> s) and split the polynomial into W independent size-M transforms hanging
+// from nodes W .. 2W - 1 of the twiddle tree.  Wave w takes sub-transform w: ONE trip through LDS re-deals the values
+// (every thread writes its 16 / W entries of each part, wave w reads part w in SplitNtt's layout -- register m' of lane
+// l = entry l + 64 m'), two workgroup barriers; everything after that is wave-private (no barrier, the split schedule
+// of SplitNtt hides its own LDS latency).  The generic two-wave transform (PolyNtt<11,7>) needs four barriers per
+// transform, spilled 35-54 registers inside the blind rotation and conflicted in LDS; this one has the register budget
+// of the N = 1024 kernel.  The inverse is the mirror image.  `bufs` of the exchange state is the polynomial's N-word LDS
+// region; wave w uses words [w M, (w+1) M) of it as its private SplitNtt buffer -- the very words only it reads in the
+// re-deal, so no barrier is needed between the re-deal and the private transform.
+// Twiddles: `uniform` is the table of the whole polynomial (N entries, tw[i] = psi^bitrev(i)); `lane` points at the W
+// parts' OWN tables back to back, M entries each: entry i of part w = entry ((W + w) << d) + (i - 2^d) of the big table,
 // d = floor(log2 i) (host_twiddles appends them to the big table: LANE_TABLE_OFFSET).
-template <int LOGN>
-struct PairNtt {
+template <int LOGN, int LOGW>
+struct WavesNtt {
     static constexpr int N = 1 << LOGN;
-    static constexpr int LL = 7;
-    static constexpr int LANES = 128;
+    static constexpr int W = 1 << LOGW;
+    static constexpr int LL = 6 + LOGW;
+    static constexpr int LANES = 64 * W;
     static constexpr int E = N / LANES;
-    static constexpr int EH = E / 2;
-    static constexpr int M = N / 2;
-    using Half = SplitNtt<LOGN - 1, 6>;
-    static_assert(E == 16 && Half::E == 16, "two waves, 16 coefficients per lane");
-    static constexpr int LANE_TABLE_OFFSET = N;   // where the per-lane table starts inside the uploaded twiddle buffer
-    // array position of the evaluation in register m of thread t (see SplitNtt): wave w holds array half w
+    static constexpr int EP = E / W;          // registers per part after the cross stages
+    static constexpr int M = N / W;
+    using Half = SplitNtt<LOGN - LOGW, 6>;
+    static_assert(E == 16 && Half::E == 16 && (LOGW == 1 || LOGW == 2), "two or four waves, 16 coefficients per lane");
+    // where the per-lane tables start inside the uploaded twiddle buffer: [N whole][N two halves][N four quarters]
+    static constexpr int LANE_TABLE_OFFSET = LOGW * N;
+    // array position of the evaluation in register m of thread t (see SplitNtt): wave w holds array part w
     static constexpr bool HAS_EVAL_POSITION = true;
-    static constexpr int EVAL_GROUP_LOG2 = 3;
+    static constexpr int EVAL_GROUP_LOG2 = 2 + LOGW;
     __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return (t >> 6) * (uint32_t)M + ((t & 63u) << 3); }
     __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (M / 2) + (uint32_t)(m & 7); }
     __device__ static __forceinline__ Twiddles half_table(const Twiddles &tw, uint32_t w) {
@@ -310,7 +312,7 @@ struct PairNtt {
     // Where thread t parks register m of a polynomial handed over between the two components: inside the words its own wave
     // uses privately afterwards, so that no other wave has to be waited for before the inverse transform starts.
     __device__ static __forceinline__ uint32_t handoff_word(uint32_t t, int m) { return (t >> 6) * (uint32_t)M + (t & 63u) + 64u * (uint32_t)m; }
-    // which half this wave owns (wave-uniform, and known to the compiler as such)
+    // which part this wave owns (wave-uniform, and known to the compiler as such)
     __device__ static __forceinline__ uint32_t wave_of(uint32_t t) { return __builtin_amdgcn_readfirstlane(t >> 6); }
 
     struct NoHook {
@@ -319,23 +321,35 @@ struct PairNtt {
     template <int FIRST, class Hook>
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
         const uint32_t w = wave_of(t), l = t & 63u;
-        {
-            const double w0 = tw.uniform[1];
+        // cross stages: stage s pairs register m with m + (E/2 >> s) inside blocks of E >> s registers; block b uses tw[2^s + b]
 #pragma unroll
-            for (int r = 0; r < EH; r++) first_butterfly<FIRST>(x[r], x[r + EH], w0);
+        for (int s = 0; s < LOGW; s++) {
+            const int half = (E / 2) >> s;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                if (m & half) continue;
+                const double wv = tw.uniform[(1u << s) + (uint32_t)(m >> (4 - s))];
+                if (s == 0) {
+                    first_butterfly<FIRST>(x[m], x[m + half], wv);
+                } else {
+                    const double u = x[m], v = fp_mulmod(x[m + half], wv);
+                    x[m] = u + v;
+                    x[m + half] = u - v;
+                }
+            }
         }
         double *region = xc.bufs;
-        __syncthreads();   // whoever used the region before (the other wave's private transform, the caller) is done
+        __syncthreads();   // whoever used the region before (the other waves' private transforms, the caller) is done
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int q = 0; q < W; q++)
 #pragma unroll
-            for (int r = 0; r < EH; r++) region[h * M + t + (uint32_t)LANES * r] = x[h * EH + r];
+            for (int r = 0; r < EP; r++) region[q * M + t + (uint32_t)LANES * r] = x[q * EP + r];
         __syncthreads();
         double *mine = region + w * M;
 #pragma unroll
         for (int m = 0; m < E; m++) x[m] = mine[l + 64u * m];
         typename Half::Xchg hx{mine, 0, 0};
-        Half::template forward<0>(x, hx, l, half_table(tw, w), before_last, 2u + w);
+        Half::template forward<0>(x, hx, l, half_table(tw, w), before_last, (uint32_t)W + w);
     }
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         forward<0>(x, xc, t, tw, NoHook{});
@@ -343,49 +357,58 @@ struct PairNtt {
 
     struct InvUniform {
         typename Half::InvUniform half;
-        double w0;
+        double w[W - 1];   // the cross stages' twiddles, tw[1 .. W - 1]
     };
     __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t t, const Twiddles &tw) {
         InvUniform u;
-        u.half = Half::inverse_uniform(t & 63u, tw, 2u + wave_of(t));   // wave-uniform reads only: the big table
-        u.w0 = tw.uniform[1];
+        u.half = Half::inverse_uniform(t & 63u, tw, (uint32_t)W + wave_of(t));   // wave-uniform reads only: the big table
+#pragma unroll
+        for (int i = 0; i < W - 1; i++) u.w[i] = tw.uniform[1 + i];
         return u;
     }
     template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
         inverse<BOUNDED>(x, xc, t, tw, inverse_uniform(t, tw));
     }
-    // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q) -> N * coefficients, |x| <= 16 q
+    // evaluations (|x| < 2^52; BOUNDED: |x| <= 8 q) -> N * coefficients, |x| <= 8 W q
     template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &uni) {
         const uint32_t w = wave_of(t), l = t & 63u;
         double *region = xc.bufs, *mine = region + w * M;
         typename Half::Xchg hx{mine, 0, 0};
-        Half::template inverse<BOUNDED>(x, hx, l, half_table(tw, w), uni.half, 2u + w);   // <= 8 q, in the half's coefficient layout
+        Half::template inverse<BOUNDED>(x, hx, l, half_table(tw, w), uni.half, (uint32_t)W + w);   // <= 8 q, the part's coefficient layout
         Half::sync();      // the stores below stay behind the last reads of the private transform (same wave, same words)
 #pragma unroll
         for (int m = 0; m < E; m++) mine[l + 64u * m] = x[m];
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int q = 0; q < W; q++)
 #pragma unroll
-            for (int r = 0; r < EH; r++) x[h * EH + r] = region[h * M + t + (uint32_t)LANES * r];
-        // last Gentleman-Sande stage joins the halves: inputs <= 8 q each, sums <= 16 q, products < 0.8 q
+            for (int r = 0; r < EP; r++) x[q * EP + r] = region[q * M + t + (uint32_t)LANES * r];
+        // Gentleman-Sande stages join the parts, last cross stage first: inputs <= 8 q, sums double per stage (<= 8 W q <=
+        // 32 q, inside what fp_mulmod and the caller's centring accept), products < 0.8 q
 #pragma unroll
-        for (int r = 0; r < EH; r++) {
-            const double u = x[r], v = x[r + EH];
-            x[r] = u + v;
-            x[r + EH] = fp_mulmod(u - v, uni.w0);
+        for (int s = LOGW - 1; s >= 0; s--) {
+            const int half = (E / 2) >> s;
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                if (m & half) continue;
+                const double u = x[m], v = x[m + half];
+                x[m] = u + v;
+                x[m + half] = fp_mulmod(u - v, uni.w[(1 << s) - 1 + (m >> (4 - s))]);
+            }
         }
     }
 };
+template <int LOGN>
+using PairNtt = WavesNtt<LOGN, 1>;
 
 // the transform used for a shape: the split schedule where a wave holds a whole polynomial at 16 coefficients per lane,
-// the pair of split transforms where two waves hold one of twice that size
+// two or four wave-private split transforms behind one or two cross stages where two or four waves hold a larger one
 #ifndef FBS_PAIR_NTT
 #define FBS_PAIR_NTT 1   // experiments: 0 falls back to the generic two-wave transform for N = 2048
 #endif
-template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : 0>
+template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : (LL == 8 && LOGN == 12) ? 3 : 0>
 struct NttFor {
     using type = PolyNtt<LOGN, LL>;
 };
@@ -395,7 +418,11 @@ struct NttFor<LOGN, LL, 1> {
 };
 template <int LOGN, int LL>
 struct NttFor<LOGN, LL, 2> {
-    using type = PairNtt<LOGN>;
+    using type = WavesNtt<LOGN, 1>;
+};
+template <int LOGN, int LL>
+struct NttFor<LOGN, LL, 3> {
+    using type = WavesNtt<LOGN, 2>;
 };
 
 }  // namespace fbs

@@ -144,21 +144,20 @@ def _switch_fits(t, g, N):
 
 
 def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security: int | None = 128,
-                  sigma: int | None = None, poly_sizes=(9, 10, 11), n_range=(450, 1200, 4),
+                  sigma: int | None = None, poly_sizes=(9, 10, 11, 12), n_range=(450, 1200, 4),
                   floor_margin: float | None = None, groups=(1, 2)) -> Params:
     """Cheapest parameter set (n, N, l, beta, t, gamma and both noises) for plaintext modulus p and squared 2-norm
     `norm2` whose modelled margin is at least `min_margin` standard deviations -- what the reference obtains from its
     patched optimizer for (precision, sq_norm2) (experiments/add_exec_estimates.py:9-16, concrete.patch:21-27,163).
 
     security = 128: each noise is the smallest the security line allows for its dimension (`sigma_min`); n runs over
-    `n_range`, N over 2^poly_sizes (k = 1: the kernels' shape), the gadget over 1..6 levels of 3..23 bits, the key
+    `n_range`, N over 2^poly_sizes (512 .. 4096; k = 1: the kernels' shape), the gadget over 1..6 levels of 3..23 bits, the key
     switch over 1..23 levels of 1..6 bits.  security = None with `sigma`: the same search at a fixed noise (the
     reduced-noise benchmark setting).  `groups`: key bits per blind-rotation step to consider (2 = the multi-bit form: half
     the steps on bundles of three GGSW samples, 1.5x the key, more noise per step; built for N >= 1024, l <= 5, even n).
     Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
-    (p too large for N <= 2048 at this security level); with `floor_margin` the requirement is first relaxed in steps of
-    half a sigma down to that floor (p = 31 at norm2 = 325 tops out just under 6 sigma: the modulus switch at
-    N = 2048 alone leaves 5.9)."""
+    (p too large for N <= 4096 at this security level); with `floor_margin` the requirement is first relaxed in steps of
+    half a sigma down to that floor."""
     import numpy as np
     if floor_margin is not None and floor_margin < min_margin:
         m = min_margin
