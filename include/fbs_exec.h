@@ -62,7 +62,7 @@ typedef struct fbs_params {
 } fbs_params;
 
 /* Polynomial sizes.  fbs_params carries log2 N: the ring is Z_q[X]/(X^N + 1) with N a power of two (this build:
- * 256 .. 2048).  BASELINE config 5 also names "non-power-of-two N".  That is rejected on purpose, not for lack of a
+ * 256 .. 4096).  BASELINE config 5 also names "non-power-of-two N".  That is rejected on purpose, not for lack of a
  * transform (2N | q - 1 holds for N = 3 * 2^k under this modulus): for N = m * 2^k with m odd > 1, X^N + 1 is not
  * cyclotomic -- y^m + 1 is divisible by y + 1, so X^N + 1 has the factor X^(2^k) + 1 and every GLWE sample maps onto
  * the power-of-two ring of degree N/m, whose (smaller) dimension then bounds the security: N = 1536 is no safer than
