@@ -229,8 +229,8 @@ def roofline_record(prm, prof, B):
             rec["valu_frac"] = rec["frac"] = rec["achieved"] / rec["peak"]
             rec["valu_insts_per_launch"] = insts
             rec["valu_insts_per_wave_per_step"] = pmc.get("valu_per_wave_per_step")
-            rec["traffic"] = dict(bytes_per_launch=pmc.get("hbm_bytes_per_launch"), source=pmc.get("source"),
-                                  collected="offline, separate rocprofv3 --pmc passes of this command")
+            rec["traffic"] = pmc.get("hbm_bytes_per_launch")          # bytes per launch, FETCH_SIZE x2 + WRITE_SIZE
+            rec["traffic_source"] = "%s; collected offline in separate rocprofv3 --pmc passes of this command, not in this run" % pmc.get("source")
     return rec
 
 

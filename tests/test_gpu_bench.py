@@ -29,6 +29,7 @@ def test_headline_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] == "fp64_valu" and r["kernel"].startswith("k_blind_rotate<10,") and r["avg_launch_ms"] > 0
     assert 0 < r["hbm_algorithmic_frac"] and "whole_path_frac" not in r
+    assert r["traffic"] is None or (isinstance(r["traffic"], (int, float)) and "profiles/" in r["traffic_source"])
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["bit_exact_vs_gpu"] and c["cores"] >= 1 and c["cpu_model"] and c["one_thread"]["value"] > 0
     p = d["config"]["params"]
