@@ -182,3 +182,15 @@ def test_trivium_levels_are_wide():
     rec = load_fixture("trivium_stream_short128__search_p15")
     _, depth, widths = parse_fbs(rec["fbs"]).schedule()
     assert depth <= 8 and max(widths) >= 60
+
+
+def test_exec_config_hands_out_fresh_nonces_and_a_random_seed():
+    """No GPU needed: every ciphertext encrypted under one ExecConfig gets its own randomness stream, and the key seed is
+    not a constant unless the caller makes it one."""
+    from tfhe_fbs_map_amd import ExecConfig
+    cfg = ExecConfig()
+    assert cfg.take_nonces(12) == 0 and cfg.take_nonces(5) == 12 and cfg.take_nonces(1) == 17
+    a, b = ExecConfig().key_seed(), ExecConfig().key_seed()
+    assert a != b and cfg.key_seed() == cfg.key_seed()
+    fixed = ExecConfig(seed=7, nonce0=100)
+    assert fixed.key_seed() == 7 and fixed.take_nonces(9) == 100 and fixed.take_nonces(9) == 100     # explicit = reproducible

@@ -211,3 +211,12 @@ def test_eval_draws_fresh_randomness_every_call():
     assert first == 4 * len(rec["program_inputs"]) and cfg.seed is not None
     assert_outputs_equal(env.eval(ins, config=cfg), expect)
     assert cfg._next_nonce == 2 * first
+
+
+def test_empty_inputs_give_empty_outputs(cfg15):
+    """The reference reshapes whatever it is given (fbs_exec_env.py:213-214): zero samples in, zero samples out."""
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture("full_adder__search_p7")
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+    out = env.eval({n: [] for n in rec["program_inputs"]}, config=cfg15)
+    assert set(out) == set(rec["outputs"]) and all(len(v) == 0 for v in out.values())

@@ -240,8 +240,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const dou
     const uint32_t col0 = (((bx & 7u) << 1) | ((bx >> 3) & 1u) | ((bx >> 4) << 4)) * COLS;
     if (col0 > a.n) return;
     const uint32_t tg = a.t * a.gamma;
-    const uint32_t dmask = (1u << a.gamma) - 1u;
-    const int half_base = 1 << (a.gamma - 1);
     const uint32_t slice_len = (a.D + WAVES - 1) / WAVES;
 
     double acc[CPL][COLS];
@@ -257,9 +255,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const dou
         for (uint32_t idx = threadIdx.x; idx < WAVES * JT * CTS; idx += THREADS) {
             const uint32_t jj = idx % JT, q = (idx / JT) % CTS, sl = idx / (JT * CTS);
             const uint32_t j = sl * slice_len + r0 + jj;
-            uint32_t v = a.offs;                                  // a missing ciphertext or word: all digits zero
+            // fields digit + B/2 with their top bits flipped = the balanced digits in two's complement, ready for a signed
+            // bit-field extract (a missing ciphertext or word: all digits zero)
+            uint32_t v = 0;
             const uint64_t *row = ct_ptr[q];
-            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg, a.offs);
+            if (row && r0 + jj < slice_len && j < a.D) v = ks_round(row[j], tg, a.offs) ^ a.offs;
             tile[(sl * JT + jj) * CTS + q] = v;
         }
         __syncthreads();
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const dou
                 double d[CPL];
 #pragma unroll
                 for (int u = 0; u < CPL; u++)
-                    d[u] = (double)((int)((ab[u] >> (a.gamma * (a.t - 1 - v))) & dmask) - half_base);   // balanced digit
+                    d[u] = (double)(int)__builtin_amdgcn_sbfe(ab[u], a.gamma * (a.t - 1 - v), a.gamma);   // balanced digit
 #pragma unroll
                 for (int c = 0; c < COLS; c++) {
                     const double kw = krow[(size_t)v * a.stride + c];
