@@ -470,28 +470,15 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
                 other[2 * j] = ASSIGN ? r0 : other[2 * j] + r0;
                 other[2 * j + 1] = ASSIGN ? r1 : other[2 * j + 1] + r1;
             };
-            // The key words of pair 0 are requested before the last butterfly group of the transform; with the one-level
-            // shape there are registers to keep the words of pair j+1 in flight while pair j is consumed (vector-memory
-            // results return in order: requests must be ISSUED in the order they are consumed, hence the fences).
-#ifndef FBS_PAIRS_PIPELINE
-#define FBS_PAIRS_PIPELINE 0   // measured on the 128-bit set: 11.5 ms with the pipeline (35 registers spilled), 11.4 without
-#endif
-            constexpr bool PIPE = FBS_PAIRS_PIPELINE && ONE_LEVEL;
-            PairKeys in[PIPE ? 2 : 1];
-            W::template forward<FIRST>(x, xc, t, twf, [&] { request(std::integral_constant<int, 0>{}, in[0]); });
+            // The key words of pair 0 are requested before the last butterfly group of the transform, those of pair j right
+            // before it is consumed (keeping pair j+1 in flight as well was measured: 35 registers spilled, no gain).
+            PairKeys in;
+            W::template forward<FIRST>(x, xc, t, twf, [&] { request(std::integral_constant<int, 0>{}, in); });
             static_assert(E == 16, "eight register pairs, written out");
 #define FBS_PAIR_STEP(J)                                                                                    \
-    if constexpr (PIPE) {                                                                                   \
-        if constexpr ((J) + 1 < E / 2) {                                                                    \
-            request(std::integral_constant<int, ((J) + 1 < E / 2 ? (J) + 1 : 0)>{}, in[((J) + 1) & 1]);      \
-            __builtin_amdgcn_sched_barrier(0);                                                              \
-        }                                                                                                   \
-        consume(std::integral_constant<int, (J)>{}, in[PIPE ? ((J) & 1) : 0]);                              \
-    } else {                                                                                                \
-        if constexpr ((J) > 0) request(std::integral_constant<int, (J)>{}, in[0]);                          \
-        consume(std::integral_constant<int, (J)>{}, in[0]);                                                 \
-        if constexpr (!ONE_LEVEL) __builtin_amdgcn_sched_barrier(0);                                        \
-    }
+    if constexpr ((J) > 0) request(std::integral_constant<int, (J)>{}, in);                                 \
+    consume(std::integral_constant<int, (J)>{}, in);                                                        \
+    if constexpr (!ONE_LEVEL) __builtin_amdgcn_sched_barrier(0);
             FBS_PAIR_STEP(0) FBS_PAIR_STEP(1) FBS_PAIR_STEP(2) FBS_PAIR_STEP(3)
             FBS_PAIR_STEP(4) FBS_PAIR_STEP(5) FBS_PAIR_STEP(6) FBS_PAIR_STEP(7)
 #undef FBS_PAIR_STEP
