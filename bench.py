@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
     ap.add_argument("--no-secure", action="store_true", help="skip the secure-parameter-set leg")
+    ap.add_argument("--secure", action="store_true",
+                    help="circuit: the 128-bit parameter set choose_params returns for the program's (p, norm2) instead of the "
+                         "reduced-noise benchmark set")
     args = ap.parse_args(argv)
     if args.steps is None:
         args.steps = 20 if args.workload == "batch" else 2
@@ -347,7 +350,12 @@ def run_circuit(args, rank, world, local, dist):
     stats = env.stats()
     tail = args.circuit.rsplit("_p", 1)[-1].split("_")[0]            # fixtures are named <circuit>__<mapper>_p<fbs_size>
     p = int(tail) if tail.isdigit() else min_fbs_size(low["tables"])
-    prm = params_for(p)                                               # the reduced-noise benchmark set for p
+    if args.secure:
+        from tfhe_fbs_map_amd import choose_params
+        from tfhe_fbs_map_amd.params import REFERENCE_MARGIN
+        prm = choose_params(p, stats["norm2_linprod"], floor_margin=REFERENCE_MARGIN)
+    else:
+        prm = params_for(p)                                           # the reduced-noise benchmark set for p
     ctx = Context(prm, seed=1, device=local)
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
                    low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
@@ -393,8 +401,9 @@ def run_circuit(args, rank, world, local, dist):
                 scaling="strong" if args.mode == "gate" else "weak", vs_baseline=None,
                 dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)", data="synthetic",
                 config=dict(workload="BASELINE configs[3] stand-in: %s (reference mapper output, %d bootstraps, depth %d, widest level %d) "
-                                     "on %d samples%s, reduced-noise benchmark set" % (args.circuit, prog.n_bootstrap, prog.depth, prog.max_width, T,
-                                                                              " per rank" if args.mode == "sample" else ""),
+                                     "on %d samples%s, %s" % (args.circuit, prog.n_bootstrap, prog.depth, prog.max_width, T,
+                                                                              " per rank" if args.mode == "sample" else "",
+                                                                              "128-bit set chosen for its (p, norm2)" if args.secure else "reduced-noise benchmark set"),
                             mode=args.mode, rccl_ranks=world, collectives_per_step=collectives() // max(1, args.steps + args.warmup),
                             parallelism=("levels cut across ranks, one all-gather per level" if args.mode == "gate" else
                                          "samples cut across ranks, no data-path collective"),

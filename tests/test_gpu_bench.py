@@ -47,3 +47,10 @@ def test_circuit_workload(mode):
     assert d["scaling"] == ("strong" if mode == "gate" else "weak")
     assert d["config"]["wire_slots"] < d["config"]["wires"]
     assert d["value"] > 0 and set(d["kernels_ms_per_step"]) == {"keyswitch", "blind_rotate", "lincomb"}
+
+
+def test_circuit_workload_at_the_secure_set():
+    d = run_bench("--workload", "circuit", "--mode", "gate", "--circuit", "adder8__search_p15", "--samples", "8",
+                  "--steps", "1", "--warmup", "1", "--secure")
+    assert d["decrypt_ok"] and d["config"]["params"]["security_bits_estimate"] >= 127.9
+    assert "128-bit" in d["config"]["workload"]
