@@ -160,6 +160,19 @@ typedef struct fbs_program_desc {
 } fbs_program_desc;
 
 int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset *tv, fbs_prog **out);
+/* The same with options.  FBS_LOAD_FUSE_TABLES: several tables on ONE blind rotation (the reference's
+ * one-gate-one-bootstrap lowering puts several tables on one linear combination, fbs_mapper/map_to_fbs.py:41-45, and its
+ * CSE merges identical tables only, fbs_exec_env.py:93-100).  A source wire that two or more Bootstraps read is rotated
+ * ONCE, from the table-independent test vector TV_0 = Delta/2 (1 + X + .. + X^(N-1)); each table F is then cut out of that
+ * accumulator by a product with the small integer polynomial D_F (TV_F = TV_0 * D_F; multi-value bootstrap, Carpov,
+ * Izabachene, Mollimard, CT-RSA 2019) and a sample extraction.  Same decrypted results; the noise variance of such an
+ * output is |D_F|^2 times that of an ordinary bootstrap (fbs_table_fusion_norm2: the caller's parameter choice must carry
+ * it), and the ciphertexts differ from the unfused program's.  Levels of a fused program run whole (fbs_eval,
+ * fbs_eval_dev, fbs_level_bootstrap_dev over the full range without d_rows); slicing one across GPUs is refused. */
+#define FBS_LOAD_FUSE_TABLES 1u
+int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset *tv, uint32_t flags, fbs_prog **out);
+/* |D_F|^2 of table `table` of the set: the factor by which sharing a rotation multiplies its output noise variance */
+int fbs_table_fusion_norm2(const fbs_tvset *tv, uint32_t table, uint64_t *norm2);
 void fbs_program_destroy(fbs_prog *prog);
 /* depth (number of bootstrap levels) and the widest level, as scheduled */
 int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap);
@@ -194,6 +207,8 @@ typedef struct fbs_layout {
     uint32_t n_bootstrap;  /* bootstraps in the program                                        */
     uint32_t n_keyswitch;  /* key switches in the program (<= n_bootstrap: shared sources)     */
     uint32_t n_inputs, n_outputs;
+    uint32_t n_rotations;  /* blind rotations per sample (< n_bootstrap when tables share them)       */
+    uint32_t reserved;
 } fbs_layout;
 int fbs_program_layout(const fbs_prog *prog, fbs_layout *out);
 int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources);

@@ -481,6 +481,66 @@ int orc_build_tv(const orc_ctx *c, const int32_t *table, uint32_t len, uint64_t 
 }
 
 /* ------------------------------------------------------------------------ */
+/* several tables on ONE blind rotation ("multi-value bootstrap": Carpov, Izabachene, Mollimard, "New techniques for
+ * multi-value input homomorphic evaluation and applications", CT-RSA 2019, section 3 -- [NOT IN REFERENCE]: the reference
+ * emits several tables per linear combination, fbs_mapper/map_to_fbs.py:41-45, and evaluates them in clear).
+ * With TV_0 = delta_half * (1 + X + ... + X^(N-1)) and (1 + X + ... + X^(N-1)) (1 - X) = 1 - X^N = 2 in Z[X]/(X^N+1):
+ *     TV_F = delta_half * G(X)   (G_j = +-(2 f - cst), orc_build_tv)   =   TV_0 * D_F,   D_F = G (1 - X) / 2,
+ * an INTEGER polynomial (all G_j have the parity of cst) that is zero except where the table changes value.  So
+ * X^-phase * TV_F = (X^-phase * TV_0) * D_F: one blind rotation of the table-independent TV_0, then per table a product of
+ * the accumulator by the small polynomial D_F and a sample extraction.  The output noise variance grows by |D_F|^2. */
+/* ------------------------------------------------------------------------ */
+void orc_tv0(const orc_ctx *c, uint64_t *tv) {
+    for (uint32_t j = 0; j < c->N; j++) tv[j] = c->delta_half;
+}
+
+/* diff[N] = D_F (dense, small signed integers), *post_add as orc_build_tv; returns the same error */
+int orc_build_tv_diff(const orc_ctx *c, const int32_t *table, uint32_t len, int32_t *diff, uint64_t *post_add) {
+    uint32_t p = c->p.p_msg, N = c->N;
+    if (len == 0 || len > 2 * p) return -1;
+    int64_t cst = 0;
+    if (len > p) {
+        cst = (int64_t)table[0] + table[p];
+        for (uint32_t i = 0; i + p < len; i++)
+            if ((int64_t)table[i] + table[i + p] != cst) return -1;
+    }
+    int64_t *g = malloc((size_t)N * sizeof *g);
+    for (uint32_t j = 0; j < N; j++) {
+        uint64_t x = ((uint64_t)j * 2 * p + N) / (2ull * N);
+        int64_t f = x < p ? (x < len ? table[x] : 0) : (0 < len ? table[0] : 0);
+        g[j] = x < p ? 2 * f - cst : -(2 * f - cst);
+    }
+    /* (G (1 - X))_j = G_j - G_(j-1), and G_0 + G_(N-1) at j = 0 (X^N = -1) */
+    for (uint32_t j = 0; j < N; j++) {
+        int64_t d = j ? g[j] - g[j - 1] : g[0] + g[N - 1];
+        diff[j] = (int32_t)(d / 2); /* exact: see above */
+    }
+    free(g);
+    *post_add = gl_mul(gl_from_i64(cst), c->delta_half);
+    return 0;
+}
+
+/* ct_out = SampleExtract_0(acc * D_F) + post_add, acc = the (k+1) polynomials the blind rotation of TV_0 left */
+void orc_multi_extract(const orc_ctx *c, const uint64_t *acc, const int32_t *diff, uint64_t post_add, uint64_t *ct_big) {
+    uint32_t N = c->N, k = c->p.k;
+    uint64_t *prod = calloc((size_t)(k + 1) * N, 8);
+    for (uint32_t cc = 0; cc <= k; cc++) {
+        const uint64_t *a = acc + (size_t)cc * N;
+        uint64_t *o = prod + (size_t)cc * N;
+        for (uint32_t i = 0; i < N; i++) {
+            if (!diff[i]) continue;
+            uint64_t d = gl_from_i64(diff[i]);
+            for (uint32_t m = 0; m < N; m++) { /* X^i * a: coefficient m is a[m - i], negated when it wrapped */
+                uint64_t t = m >= i ? gl_mul(d, a[m - i]) : gl_neg(gl_mul(d, a[m + N - i]));
+                o[m] = gl_add(o[m], t);
+            }
+        }
+    }
+    orc_sample_extract(c, prod, post_add, ct_big);
+    free(prod);
+}
+
+/* ------------------------------------------------------------------------ */
 /* the path                                                                  */
 /* ------------------------------------------------------------------------ */
 void orc_lincomb(const orc_ctx *c, const uint64_t *const *srcs, const int64_t *coefs, uint32_t n_src,

@@ -104,6 +104,13 @@ void orc_phase(const orc_ctx *c, const uint64_t *cts, size_t count, uint64_t *ph
  * table violates the negacyclic contract for p (map_to_fbs.py:81-98) */
 int orc_build_tv(const orc_ctx *c, const int32_t *table, uint32_t len, uint64_t *tv, uint64_t *post_add);
 
+/* --- several tables on one blind rotation (multi-value bootstrap, CIM19; see tfhe_oracle.c) --- */
+void orc_tv0(const orc_ctx *c, uint64_t *tv);                    /* delta_half * (1 + X + .. + X^(N-1)) */
+/* diff[N]: the integer polynomial D_F with TV_F = TV_0 * D_F; post_add and errors as orc_build_tv */
+int orc_build_tv_diff(const orc_ctx *c, const int32_t *table, uint32_t len, int32_t *diff, uint64_t *post_add);
+/* ct_out = SampleExtract_0(acc * D_F) + post_add for acc = orc_blind_rotate(ms, TV_0) */
+void orc_multi_extract(const orc_ctx *c, const uint64_t *acc, const int32_t *diff, uint64_t post_add, uint64_t *ct_big);
+
 /* --- the path, stage by stage ------------------------------------------- */
 void orc_lincomb(const orc_ctx *c, const uint64_t *const *srcs, const int64_t *coefs, uint32_t n_src,
                  int64_t const_coef, uint64_t *out);

@@ -69,6 +69,10 @@ def lib():
         L.orc_blind_rotate.argtypes = [vp, vp, vp, vp]
         L.orc_sample_extract.argtypes = [vp, vp, u64, vp]
         L.orc_bootstrap.argtypes = [vp, vp, vp, u64, vp]
+        L.orc_tv0.argtypes = [vp, vp]
+        L.orc_build_tv_diff.restype = C.c_int
+        L.orc_build_tv_diff.argtypes = [vp, vp, u32, vp, C.POINTER(u64)]
+        L.orc_multi_extract.argtypes = [vp, vp, vp, u64, vp]
         L.orc_bootstrap_batch.restype = C.c_int
         L.orc_bootstrap_batch.argtypes = [vp, vp, vp, vp, vp, sz, vp, C.c_int]
         _lib = L
@@ -181,6 +185,41 @@ class Oracle:
         acc = np.empty((self.p["k"] + 1) * self.N, np.uint64)
         lib().orc_blind_rotate(self._h, ms.ctypes.data, tv.ctypes.data, acc.ctypes.data)
         return acc
+
+    # ---- several tables on one blind rotation (multi-value bootstrap, see tfhe_oracle.c) ----
+    def tv0(self):
+        tv = np.empty(self.N, np.uint64)
+        lib().orc_tv0(self._h, tv.ctypes.data)
+        return tv
+
+    def build_tv_diff(self, table):
+        """(D_F as int32[N], post_add) with TV_F = TV_0 * D_F."""
+        t = _c(table, np.int32)
+        diff = np.empty(self.N, np.int32)
+        post = C.c_uint64()
+        rc = lib().orc_build_tv_diff(self._h, t.ctypes.data, len(t), diff.ctypes.data, C.byref(post))
+        if rc != 0:
+            raise ValueError(f"table {list(t)} is not negacyclic-valid for p={self.p['p_msg']}")
+        return diff, post.value
+
+    def multi_extract(self, acc, diff, post_add=0):
+        acc, diff = _c(acc, np.uint64), _c(diff, np.int32)
+        out = np.empty(self.ctw, np.uint64)
+        lib().orc_multi_extract(self._h, acc.ctypes.data, diff.ctypes.data, post_add, out.ctypes.data)
+        return out
+
+    def bootstrap_multi(self, cts, tables):
+        """Every table of `tables` on every ciphertext of `cts` with ONE blind rotation per ciphertext.
+        Returns [len(tables)][len(cts)][ct_words]."""
+        cts = _c(cts, np.uint64).reshape(-1, self.ctw)
+        tv0 = self.tv0()
+        diffs = [self.build_tv_diff(t) for t in tables]
+        out = np.empty((len(tables), len(cts), self.ctw), np.uint64)
+        for i, ct in enumerate(cts):
+            acc = self.blind_rotate(self.modswitch(self.keyswitch(ct)), tv0)
+            for j, (d, post) in enumerate(diffs):
+                out[j, i] = self.multi_extract(acc, d, post)
+        return out
 
     def bootstrap_batch(self, cts, tables, table_ids=None, threads=0):
         """tables: list of int lists.  Returns (cts_out, threads_used)."""

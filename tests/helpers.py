@@ -56,12 +56,17 @@ def assert_outputs_equal(got, expected):
             assert np.array_equal(np.asarray(g).reshape(-1), e), "output %s differs" % k
 
 
-def oracle_eval_program(orc, ops, outputs, in_cts):
+def oracle_eval_program(orc, ops, outputs, in_cts, fuse=False):
     """Run a program (oracle.lut_oracle.read_fbs form) on ciphertexts with the C oracle.
-    in_cts: {input name: [T][ct_words]}.  Returns {wire name: [T][ct_words]} for all wires."""
+    in_cts: {input name: [T][ct_words]}.  Returns {wire name: [T][ct_words]} for all wires.
+    fuse: a wire that two or more bootstraps read is rotated once and every table cut out of that accumulator
+    (oracle bootstrap_multi) -- what a program loaded with FBS_LOAD_FUSE_TABLES computes."""
     wires = dict(in_cts)
     T = len(next(iter(in_cts.values()))) if in_cts else 1
-    tv_cache = {}
+    readers = {}
+    for op in ops:
+        if op[0] == "boot":
+            readers.setdefault(op[2], []).append(op)
     for op in ops:
         if op[0] == "lin":
             _, name, terms, const = op
@@ -69,6 +74,13 @@ def oracle_eval_program(orc, ops, outputs, in_cts):
             for s in range(T):
                 out[s] = orc.lincomb([wires[src][s] for _, src in terms], [c for c, _ in terms], const)
             wires[name] = out
+        elif fuse and len(readers[op[2]]) >= 2:
+            if op[1] in wires:
+                continue                                        # computed with the first gate of its source
+            group = readers[op[2]]
+            res = orc.bootstrap_multi(wires[op[2]], [g[3] for g in group])
+            for g, r in zip(group, res):
+                wires[g[1]] = r
         else:
             _, name, src, table = op
             res, _ = orc.bootstrap_batch(wires[src], [table], None)

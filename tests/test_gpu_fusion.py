@@ -1,0 +1,191 @@
+"""Several tables on ONE blind rotation (include/fbs_exec.h FBS_LOAD_FUSE_TABLES).  The reference's
+one-gate-one-bootstrap lowering puts several tables on one linear combination (map_to_fbs.py:41-45; its CSE merges
+identical tables only, fbs_exec_env.py:93-100).  A fused program rotates such a source once, from the table-independent
+TV_0, and cuts every table out of that accumulator (TV_F = TV_0 * D_F).  Checked word for word against the CPU oracle's
+restatement of the same construction, and at the decrypted level against the reference's cleartext goldens."""
+import numpy as np
+import pytest
+
+from oracle import lut_oracle, tfhe_oracle as orc
+from tests.helpers import load_fixture, oracle_eval_program, subsample
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from tfhe_fbs_map_amd import _native
+    return _native
+
+
+def load(nat, prm, text, inputs, seed=6, fuse=True, merge=True):
+    from tfhe_fbs_map_amd import parse_fbs
+    ctx = nat.Context(prm, seed=seed)
+    env = parse_fbs(text, inputs=inputs, merge_linear_prods=merge)
+    low = env.lower()
+    tv = ctx.tvset(low["tables"])
+    prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
+                       low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fuse)
+    return ctx, low, tv, prog
+
+
+def params_for(toy_params, rec):
+    ops, _ = lut_oracle.read_fbs(rec["fbs"])
+    p = max(7, max(len(op[3]) for op in ops if op[0] == "boot"))
+    return toy_params.replace(p_msg=p)
+
+
+@pytest.mark.parametrize("name", ["adder8__basic_p2", "2_input_gates__basic_p2", "half_adder__basic_p2"])
+def test_fused_program_equals_the_oracle_and_the_reference(nat, toy_params, name):
+    T = 3
+    rec = load_fixture(name)
+    prm = params_for(toy_params, rec)
+    ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    ops, outs = lut_oracle.read_fbs(rec["fbs"])
+    distinct = len({op[2] for op in ops if op[0] == "boot"})
+    assert prog.n_rotations == distinct < prog.n_bootstrap          # one rotation per source, however many tables read it
+    assert prog.n_keyswitch == distinct
+    ins, expect = subsample(rec, T)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
+    got = prog.eval(cts, T)
+    o = orc.Oracle(prm, seed=6)
+    in_cts = {n: cts[i] for i, n in enumerate(low["input_names"])}
+    fused = oracle_eval_program(o, ops, outs, in_cts, fuse=True)
+    plain = oracle_eval_program(o, ops, outs, in_cts, fuse=False)
+    differs = False
+    for k, (out_name, src) in enumerate(outs):
+        if src in ("0", "1"):
+            continue
+        assert np.array_equal(got[k], fused[src]), out_name
+        assert np.array_equal(ctx.decrypt(got[k]), expect[out_name])
+        differs |= not np.array_equal(fused[src], plain[src])
+    assert differs                                                    # other ciphertexts than the unfused program's, same plaintexts
+
+
+def test_a_program_with_nothing_to_share_is_unchanged(nat, toy_params):
+    rec = load_fixture("aes_sbox__basic_p2")
+    prm = params_for(toy_params, rec)
+    ctx, low, tv, fused = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    assert fused.n_rotations == fused.n_bootstrap
+    plain = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
+                        low["term_coef"], low["term_src"], low["out_wire"])
+    ins, _ = subsample(rec, 2)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=3)
+    assert np.array_equal(fused.eval(cts, 2), plain.eval(cts, 2))
+
+
+MULTI = """m1 = 1 * a + 4 * b + 8 * c
+m2 = Bootstrap(m1, [0, 1, 2, 1, 0, 2, 1, 2, 1, 0, 1, 2, 0, 1])
+m3 = Bootstrap(m1, [1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0])
+m4 = Bootstrap(m1, [0, 0, 0, 1, 0, 1, 1, 1, 1, 1, 0, 1, 0, 0])
+m5 = 1 * a + 1 * b
+m6 = Bootstrap(m5, [0, 1, 1])
+m7 = 1 * m6 + 2 * m3 + 3 * a
+m8 = Bootstrap(m7, [0, 1, 1, 0, 1, 0, 0])
+m9 = Bootstrap(m7, [0, 0, 0, 1, 0, 1, 1])
+m10 = Bootstrap(m7, [1, 1, 0, 0, 0, 0, 1])
+Output o1 = m2
+Output o2 = m8
+Output o3 = m9
+Output o4 = m10
+Output o5 = m6
+Output o6 = m4
+"""
+
+
+@pytest.mark.parametrize("log_n,group", [(10, 1), (11, 1), (11, 2), (8, 1)])
+def test_multi_valued_and_negacyclic_tables_share_a_rotation(nat, log_n, group):
+    """Tables with values beyond {0, 1}, negacyclic tables (c = 1, 2), a source with one reader beside shared ones; at N = 2048 the accumulator is written by four waves, with two key bits per step by the pairs kernel."""
+    from tfhe_fbs_map_amd import Params
+    prm = Params(n=12, log_n_poly=log_n, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 8, bsk_group=group)
+    T = 8
+    ctx, low, tv, prog = load(nat, prm, MULTI, ["a", "b", "c"])
+    assert (prog.n_bootstrap, prog.n_rotations, prog.n_keyswitch) == (7, 3, 3)
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2, (3, T))
+    cts = ctx.encrypt(bits, nonce0=2)
+    got = prog.eval(cts, T)
+    ops, outs = lut_oracle.read_fbs(MULTI)
+    o = orc.Oracle(prm, seed=6)
+    wires = oracle_eval_program(o, ops, outs, {n: cts[i] for i, n in enumerate(low["input_names"])}, fuse=True)
+    clear = lut_oracle.eval_fbs_text(MULTI, {n: bits[i] for i, n in enumerate(low["input_names"])})
+    for k, (out_name, src) in enumerate(outs):
+        assert np.array_equal(got[k], wires[src]), out_name
+        assert np.array_equal(ctx.decrypt(got[k]) % (2 * prm.p_msg), np.asarray(clear[out_name]) % (2 * prm.p_msg)), out_name
+    # the factor the output noise variance grows by, against the oracle's own polynomial D_F
+    for t, table in enumerate(low["tables"]):
+        d, _ = o.build_tv_diff(table)
+        assert tv.fusion_norm2(t) == int((d.astype(np.int64) ** 2).sum())
+
+
+def test_tables_with_negative_values_below_the_facade(nat, toy_params):
+    """c = 0 tables (f(x + p) = -f(x)) and negative entries: not expressible through the builder (its tables start at
+    0, fbs_exec_env.py:76), legal at the C ABI."""
+    prm = toy_params
+    tables = [[0, 1, 2, 3, 4, 5, 6, 2, 1, 0, -1, -2, -3, -4], [0, 0, 0, 1, 0, 1, 1, 0, 0, 0, -1, 0, -1, -1], [3, -2, 5, 0, 0, -6, 1]]
+    ctx = nat.Context(prm, seed=6)
+    tv = ctx.tvset(tables)
+    #       m1 = a + 4 b + 8 c           three tables on m1
+    prog = nat.Program(ctx, tv, 3, [0, 1, 1, 1], [0, 3, 3, 3], [3, 0, 1, 2], [0, 0, 0, 0], [1, 4, 8], [0, 1, 2], [4, 5, 6],
+                       fuse_tables=True)
+    assert (prog.n_bootstrap, prog.n_rotations) == (3, 1)
+    T = 8
+    bits = np.array([[0, 1, 0, 1, 0, 1, 0, 1], [0, 0, 1, 1, 0, 0, 1, 1], [0, 0, 0, 0, 1, 1, 1, 1]])
+    cts = ctx.encrypt(bits, nonce0=4)
+    got = prog.eval(cts, T)
+    o = orc.Oracle(prm, seed=6)
+    ops = [("lin", "m1", [(1, "a"), (4, "b"), (8, "c")], 0)] + [("boot", "t%d" % i, "m1", t) for i, t in enumerate(tables)]
+    wires = oracle_eval_program(o, ops, [], dict(a=cts[0], b=cts[1], c=cts[2]), fuse=True)
+    v = bits[0] + 4 * bits[1] + 8 * bits[2]
+    for i, t in enumerate(tables):
+        assert np.array_equal(got[i], wires["t%d" % i])
+        full = t if len(t) == 14 else t + [-x for x in t]          # a table that stops at p continues negacyclically
+        assert np.array_equal(ctx.decrypt(got[i]) % 14, np.array([full[x] for x in v]) % 14)
+
+
+def test_levels_of_a_fused_program_run_whole(nat, toy_params):
+    import torch
+    rec = load_fixture("adder8__basic_p2")
+    prm = params_for(toy_params, rec)
+    T = 4
+    ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    ins, _ = subsample(rec, T)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
+    ref = prog.eval(cts, T)
+    ctw = prm.ct_words
+    wires = torch.zeros((prog.n_slots, T, ctw), dtype=torch.int64, device="cuda")
+    wires[torch.from_numpy(prog.in_slot.astype(np.int64)).cuda()] = torch.from_numpy(cts.view(np.int64)).cuda()
+    sliced = 0
+    for L in range(prog.depth + 1):
+        prog.level_lincomb_dev(L, wires.data_ptr(), T, 0, T)
+        if L == prog.depth:
+            break
+        total = prog.level_width[L] * T
+        try:                                                   # half a level: refused where tables share a rotation
+            rows = torch.empty((total // 2, ctw), dtype=torch.int64, device="cuda")
+            prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, 0, total // 2, d_rows=rows.data_ptr())
+        except nat.FbsError as e:
+            assert "cannot be sliced" in str(e)
+            sliced += 1
+        prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, 0, total)
+    ctx.sync()
+    assert sliced > 0
+    got = wires.cpu().numpy().view(np.uint64)
+    for k, slot in enumerate(prog.out_slot.tolist()):
+        if slot >= 0:
+            assert np.array_equal(got[slot], ref[k])
+
+
+def test_fused_samples_in_chunks(nat, toy_params, monkeypatch):
+    rec = load_fixture("adder8__basic_p2")
+    prm = params_for(toy_params, rec)
+    T = 29
+    ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    ins, expect = subsample(rec, T)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
+    ref = prog.eval(cts, T)
+    monkeypatch.setenv("FBS_WIRE_BUDGET_MB", "2")
+    ctx2, low2, tv2, prog2 = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    assert np.array_equal(prog2.eval(cts, T), ref)
+    for k, name in enumerate(low["out_names"]):
+        assert np.array_equal(ctx2.decrypt(ref[k]), expect[name])

@@ -32,7 +32,7 @@ class _Params(C.Structure):
 
 class _Layout(C.Structure):
     _fields_ = [(f, C.c_uint32) for f in ("n_slots", "n_levels", "max_width", "max_sources", "n_bootstrap", "n_keyswitch",
-                                          "n_inputs", "n_outputs")]
+                                          "n_inputs", "n_outputs", "n_rotations", "reserved")]
 
 
 class _ProgramDesc(C.Structure):
@@ -144,6 +144,8 @@ def _load():
         "fbs_lincomb_dev": (i32, [vp, vp, sz, u32, vp, vp, vp, vp, vp, vp]),
         "fbs_bootstrap_wires_dev": (i32, [vp, vp, vp, sz, u32, vp, vp, vp, sz, sz, vp]),
         "fbs_program_load": (i32, [vp, C.POINTER(_ProgramDesc), vp, C.POINTER(vp)]),
+        "fbs_program_load_ex": (i32, [vp, C.POINTER(_ProgramDesc), vp, u32, C.POINTER(vp)]),
+        "fbs_table_fusion_norm2": (i32, [vp, u32, C.POINTER(u64)]),
         "fbs_program_destroy": (None, [vp]),
         "fbs_program_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "fbs_eval": (i32, [vp, vp, vp, sz, vp]),
@@ -176,7 +178,8 @@ EXPORTED_SYMBOLS = (
     "fbs_poly_size_check", "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
-    "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_destroy", "fbs_program_info",
+    "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_load_ex", "fbs_table_fusion_norm2", "fbs_program_destroy",
+    "fbs_program_info",
     "fbs_searcher_create", "fbs_searcher_destroy", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms",
     "fbs_search_lincomb_coefs", "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
     "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
@@ -204,6 +207,12 @@ class TvSet:
         ctx._check(lib.fbs_tvset_create(ctx._h, _ptr(vals), _ptr(off), len(self.tables), C.byref(h)))
         self._h = h
 
+    def fusion_norm2(self, table):
+        """|D_F|^2 of table `table`: what sharing a blind rotation multiplies its output noise variance by."""
+        out = C.c_uint64()
+        self.ctx._check(lib.fbs_table_fusion_norm2(self._h, table, C.byref(out)))
+        return out.value
+
     def __del__(self):
         if getattr(self, "_h", None) and self.ctx._h and lib is not None:
             lib.fbs_tvset_destroy(self._h)
@@ -211,20 +220,26 @@ class TvSet:
 
 
 class Program:
-    def __init__(self, ctx, tvset, n_inputs, kind, arg0, arg1, const_coef, term_coef, term_src, out_wire):
+    FUSE_TABLES = 1    # FBS_LOAD_FUSE_TABLES
+
+    def __init__(self, ctx, tvset, n_inputs, kind, arg0, arg1, const_coef, term_coef, term_src, out_wire, fuse_tables=False):
+        """fuse_tables: the tables of a source that several Bootstraps read share ONE blind rotation
+        (include/fbs_exec.h, FBS_LOAD_FUSE_TABLES)."""
         self.ctx, self.tvset = ctx, tvset
+        self.fused = bool(fuse_tables)
         self._keep = [_c(kind, np.uint8), _c(arg0, np.uint32), _c(arg1, np.uint32), _c(const_coef, np.int64),
                       _c(term_coef, np.int64), _c(term_src, np.uint32), _c(out_wire, np.int64)]
         k = self._keep
         desc = _ProgramDesc(n_inputs, len(k[0]), len(k[4]), len(k[6]), *[_ptr(a) for a in k])
         h = C.c_void_p()
-        ctx._check(lib.fbs_program_load(ctx._h, C.byref(desc), tvset._h, C.byref(h)))
+        ctx._check(lib.fbs_program_load_ex(ctx._h, C.byref(desc), tvset._h, self.FUSE_TABLES if fuse_tables else 0, C.byref(h)))
         self._h = h
         self.n_inputs, self.n_outputs = n_inputs, len(k[6])
         lay = _Layout()
         ctx._check(lib.fbs_program_layout(h, C.byref(lay)))
         self.depth, self.max_width, self.n_bootstrap = lay.n_levels, lay.max_width, lay.n_bootstrap
         self.n_slots, self.n_keyswitch, self.max_sources = lay.n_slots, lay.n_keyswitch, lay.max_sources
+        self.n_rotations = lay.n_rotations
         self.in_slot = np.empty(self.n_inputs, np.uint32)
         self.out_slot = np.empty(self.n_outputs, np.int64)
         ctx._check(lib.fbs_program_io_slots(h, _ptr(self.in_slot), _ptr(self.out_slot)))

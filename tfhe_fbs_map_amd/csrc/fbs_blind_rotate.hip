@@ -275,6 +275,11 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
     if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
     uint64_t *out = gate_out(a.gv, f, a.ct_words);
     if (comp == 0) {
 #pragma unroll
@@ -503,6 +508,11 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
 
     if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
     uint64_t *out = gate_out(a.gv, f, a.ct_words);
     if (comp == 0) {
 #pragma unroll
@@ -629,7 +639,8 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     a.l = p.l_bsk;
     a.beta = p.beta_bsk;
     a.ct_words = ctx->D + 1;
-    a.n_tables = std::max(1u, tv->n_tables);
+    // (entry n_tables of the set is TV_0: selectable only by the rotations of a fused program, whose ids the host wrote)
+    a.n_tables = gv.acc_rows ? tv->n_tables + 1 : std::max(1u, tv->n_tables);
     const size_t count = gv.count;
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");

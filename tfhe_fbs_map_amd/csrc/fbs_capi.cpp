@@ -38,12 +38,19 @@ struct BootStage {
     uint32_t *d_source_of = nullptr;   // [n_gates]   index into d_src_slot
     uint32_t *d_dst = nullptr, *d_table = nullptr;   // [n_gates]
     std::vector<uint32_t> source_of;   // host copy: which key switches a slice of the level needs
+    // Fused programs (FBS_LOAD_FUSE_TABLES): the tables of a source that several read are served by ONE gate of the list
+    // above -- the rotation of TV_0 (table id = the set's n_tables, dst = 0x80000000 | shared index) -- and one entry each
+    // of the extraction list below (k_multi_extract)
+    uint32_t n_shared = 0, n_extract = 0;
+    uint32_t *d_x_row = nullptr, *d_x_table = nullptr, *d_x_dst = nullptr;   // [n_extract] shared index, table, wire slot
 };
 struct fbs_prog {
     fbs_ctx *ctx = nullptr;
     const fbs_tvset *tv = nullptr;
     uint32_t n_inputs = 0, n_instr = 0, n_outputs = 0, n_wires = 0, n_slots = 0;
     uint32_t depth = 0, max_width = 0, max_sources = 0, n_bootstrap = 0, n_keyswitch = 0;
+    uint32_t n_rotations = 0, max_shared = 0;   // blind rotations per sample (= n_bootstrap unless fused); shared rotations of the widest level
+    bool fused = false;
     std::vector<uint32_t> in_slot;    // [n_inputs]
     std::vector<int64_t> out_slot;    // [n_outputs]  slot, or -1-c for the constant c
     // schedule: for level L = 0..depth: lincomb stages (dependency order), then the bootstraps of level L+1
@@ -82,6 +89,17 @@ static int ensure_ms(fbs_ctx *ctx, size_t count) {
     ctx->ms_capacity = 0;
     FBS_HIP(ctx, hipMalloc(&ctx->d_ms, count * (ctx->p.n + 1) * sizeof(uint32_t)));
     ctx->ms_capacity = count;
+    return FBS_OK;
+}
+
+static int ensure_acc(fbs_ctx *ctx, size_t rows) {
+    if (rows <= ctx->acc_capacity) return FBS_OK;
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
+    if (ctx->d_acc) (void)hipFree(ctx->d_acc);
+    ctx->d_acc = nullptr;
+    ctx->acc_capacity = 0;
+    FBS_HIP(ctx, hipMalloc(&ctx->d_acc, rows * 2 * (size_t)ctx->N * 8));
+    ctx->acc_capacity = rows;
     return FBS_OK;
 }
 
@@ -193,7 +211,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_acc,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
@@ -266,20 +284,39 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
     tv->ctx = ctx;
     tv->n_tables = n_tables;
     const uint32_t N = ctx->N;
-    std::vector<uint64_t> host((size_t)std::max(1u, n_tables) * N, 0);
-    tv->post.assign(std::max(1u, n_tables), 0);
+    // the tables, then TV_0 (index n_tables): what a rotation shared by several tables starts from
+    std::vector<uint64_t> host((size_t)(n_tables + 1) * N, 0);
+    tv->post.assign((size_t)n_tables + 1, 0);
+    tv->diff_cap = ctx->p.p_msg + 1;
+    std::vector<uint32_t> dpos((size_t)std::max(1u, n_tables) * tv->diff_cap, 0), dn(std::max(1u, n_tables), 0);
+    std::vector<int32_t> dval((size_t)std::max(1u, n_tables) * tv->diff_cap, 0);
+    tv->diff_norm2.assign(n_tables, 0);
+    tv->fusable.assign(n_tables, 0);
     for (uint32_t t = 0; t < n_tables; t++) {
         if (table_off[t + 1] < table_off[t]) return set_error(ctx, FBS_E_INVALID, "table offsets must be non-decreasing");
-        int rc = host_build_tv(ctx, table_vals + table_off[t], table_off[t + 1] - table_off[t], host.data() + (size_t)t * N,
-                               &tv->post[t]);
+        const int32_t *vals = table_vals + table_off[t];
+        const uint32_t len = table_off[t + 1] - table_off[t];
+        int rc = host_build_tv(ctx, vals, len, host.data() + (size_t)t * N, &tv->post[t]);
+        uint64_t abs_sum = 0;
+        if (rc == FBS_OK)
+            rc = host_build_tv_diff(ctx, vals, len, dpos.data() + (size_t)t * tv->diff_cap, dval.data() + (size_t)t * tv->diff_cap, &dn[t],
+                                    &tv->diff_norm2[t], &abs_sum);
         if (rc != FBS_OK)
-            return set_error(ctx, rc, "table " + std::to_string(t) + " of length " + std::to_string(table_off[t + 1] - table_off[t]) +
+            return set_error(ctx, rc, "table " + std::to_string(t) + " of length " + std::to_string(len) +
                                           " is not evaluable by one bootstrap at p = " + std::to_string(ctx->p.p_msg));
+        tv->fusable[t] = abs_sum < (1ull << 16);   // k_multi_extract sums d * word (< 2^46) in 64 bits
     }
+    for (uint32_t j = 0; j < N; j++) host[(size_t)n_tables * N + j] = ctx->delta_half;
     hipError_t e = hipMalloc(&tv->d_tvs, host.size() * 8);
     if (e == hipSuccess) e = hipMalloc(&tv->d_post, tv->post.size() * 8);
+    if (e == hipSuccess) e = hipMalloc(&tv->d_diff_pos, dpos.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&tv->d_diff_val, dval.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&tv->d_diff_n, dn.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(tv->d_tvs, host.data(), host.size() * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(tv->d_post, tv->post.data(), tv->post.size() * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tv->d_diff_pos, dpos.data(), dpos.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tv->d_diff_val, dval.data(), dval.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tv->d_diff_n, dn.data(), dn.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         fbs_tvset_destroy(tv.release());   // frees whichever buffer was obtained
         return set_error(ctx, FBS_E_DEVICE, std::string("test-vector upload: ") + hipGetErrorString(e));
@@ -288,11 +325,20 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
     return FBS_OK;
 }
 
+int fbs_table_fusion_norm2(const fbs_tvset *tv, uint32_t table, uint64_t *norm2) {
+    if (!tv || !norm2 || table >= tv->n_tables) return FBS_E_INVALID;
+    *norm2 = tv->diff_norm2[table];
+    return FBS_OK;
+}
+
 void fbs_tvset_destroy(fbs_tvset *tv) {
     if (!tv) return;
     if (tv->ctx) (void)hipSetDevice(tv->ctx->device);
     if (tv->d_tvs) (void)hipFree(tv->d_tvs);
     if (tv->d_post) (void)hipFree(tv->d_post);
+    if (tv->d_diff_pos) (void)hipFree(tv->d_diff_pos);
+    if (tv->d_diff_val) (void)hipFree(tv->d_diff_val);
+    if (tv->d_diff_n) (void)hipFree(tv->d_diff_n);
     delete tv;
 }
 
@@ -466,11 +512,17 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
 // whole-program executor
 // ---------------------------------------------------------------------------------------------
 int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, fbs_prog **out) {
+    return fbs_program_load_ex(ctx, d, tv, 0, out);
+}
+
+int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, uint32_t flags, fbs_prog **out) {
     int rc = check_ready(ctx, tv);
     if (rc != FBS_OK) return rc;
     if (!d || !out) return set_error(ctx, FBS_E_INVALID, "null argument");
     *out = nullptr;
+    if (flags & ~(uint32_t)FBS_LOAD_FUSE_TABLES) return set_error(ctx, FBS_E_INVALID, "unknown load flag");
     std::unique_ptr<fbs_prog, void (*)(fbs_prog *)> prog(new fbs_prog, fbs_program_destroy);
+    prog->fused = (flags & FBS_LOAD_FUSE_TABLES) != 0;
     prog->ctx = ctx;
     prog->tv = tv;
     prog->n_inputs = d->n_inputs;
@@ -617,20 +669,50 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *t
         std::vector<Gate> &gates = bh[L];
         std::stable_sort(gates.begin(), gates.end(), [](const Gate &x, const Gate &y) { return x.src < y.src; });
         BootStage st;
-        st.n_gates = (uint32_t)gates.size();
-        std::vector<uint32_t> src_slot, dst, tab;
-        for (size_t g = 0; g < gates.size(); g++) {
-            if (g == 0 || gates[g].src != gates[g - 1].src) src_slot.push_back(slot[gates[g].src]);
-            st.source_of.push_back((uint32_t)src_slot.size() - 1);
-            dst.push_back(gates[g].dst);
-            tab.push_back(gates[g].tab);
+        std::vector<uint32_t> src_slot, dst, tab, x_row, x_table, x_dst;
+        for (size_t g = 0; g < gates.size();) {
+            size_t e = g;
+            while (e < gates.size() && gates[e].src == gates[g].src) e++;
+            src_slot.push_back(slot[gates[g].src]);
+            const uint32_t u = (uint32_t)src_slot.size() - 1;
+            // fused: the tables of this source that k_multi_extract can serve share one rotation of TV_0, if there are
+            // at least two of them; the others keep a rotation of their own
+            size_t n_fusable = 0;
+            if (prog->fused)
+                for (size_t i = g; i < e; i++) n_fusable += tv->fusable[gates[i].tab];
+            const bool share = n_fusable >= 2;
+            if (share) {
+                st.source_of.push_back(u);
+                dst.push_back(0x80000000u | st.n_shared);
+                tab.push_back(tv->n_tables);
+            }
+            for (size_t i = g; i < e; i++) {
+                if (share && tv->fusable[gates[i].tab]) {
+                    x_row.push_back(st.n_shared);
+                    x_table.push_back(gates[i].tab);
+                    x_dst.push_back(gates[i].dst);
+                } else {
+                    st.source_of.push_back(u);
+                    dst.push_back(gates[i].dst);
+                    tab.push_back(gates[i].tab);
+                }
+            }
+            if (share) st.n_shared++;
+            g = e;
         }
+        st.n_gates = (uint32_t)dst.size();
+        st.n_extract = (uint32_t)x_row.size();
         st.n_sources = (uint32_t)src_slot.size();
         prog->max_width = std::max(prog->max_width, st.n_gates);
         prog->max_sources = std::max(prog->max_sources, st.n_sources);
+        prog->max_shared = std::max(prog->max_shared, st.n_shared);
         prog->n_keyswitch += st.n_sources;
+        prog->n_rotations += st.n_gates;
         if ((rc = to_device(ctx, prog.get(), src_slot, &st.d_src_slot)) || (rc = to_device(ctx, prog.get(), st.source_of, &st.d_source_of)) ||
             (rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), tab, &st.d_table)))
+            return rc;
+        if (st.n_extract && ((rc = to_device(ctx, prog.get(), x_row, &st.d_x_row)) || (rc = to_device(ctx, prog.get(), x_table, &st.d_x_table)) ||
+                             (rc = to_device(ctx, prog.get(), x_dst, &st.d_x_dst))))
             return rc;
         prog->boot[L] = std::move(st);
     }
@@ -661,6 +743,8 @@ int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) {
     out->max_sources = prog->max_sources;
     out->n_bootstrap = prog->n_bootstrap;
     out->n_keyswitch = prog->n_keyswitch;
+    out->n_rotations = prog->n_rotations;
+    out->reserved = 0;
     out->n_inputs = prog->n_inputs;
     out->n_outputs = prog->n_outputs;
     return FBS_OK;
@@ -711,6 +795,10 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     const BootStage &b = prog->boot[level];
     if (f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad bootstrap range");
     if (f_begin == f_end) return FBS_OK;   // (covers s_count == 0)
+    // a level with shared rotations runs whole: the tables of one source are cut from one accumulator, there is no row of
+    // a contiguous array per bootstrap to hand out (load without FBS_LOAD_FUSE_TABLES to slice levels across GPUs)
+    if (b.n_shared && (d_rows || f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
+        return set_error(ctx, FBS_E_INVALID, "a level of a fused program cannot be sliced");
     // the key switches this slice needs: the (source, sample) pairs of its gates, as ONE flattened range.  Gates are
     // sorted by source, so only the first and the last gate of the slice can be cut short in the sample direction, and
     // only while no other gate of the slice shares their source.
@@ -737,10 +825,17 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     gv.n_gates = b.n_gates;
     rc = ensure_ms(ctx, gv.ks_count);
     if (rc != FBS_OK) return rc;
+    if (b.n_shared) {
+        if ((rc = ensure_acc(ctx, (size_t)b.n_shared * s_count)) != FBS_OK) return rc;
+        gv.acc_rows = ctx->d_acc;
+    }
     hipStream_t s = pick(ctx, stream);
     if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
     if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return rc;
     if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+    if (b.n_shared && (rc = dev_multi_extract(ctx, prog->tv, ctx->d_acc, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_row, b.d_x_table,
+                                              b.d_x_dst, s)) != FBS_OK)
+        return rc;
     return scratch_done(ctx, s);
 }
 
@@ -751,6 +846,7 @@ int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
     if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
     const BootStage &b = prog->boot[level];
     if (!d_rows || f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad row range");
+    if (b.n_shared) return set_error(ctx, FBS_E_INVALID, "a level of a fused program cannot be sliced");
     return dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, pick(ctx, stream));
 }
 
@@ -769,10 +865,11 @@ static int run_levels(fbs_ctx *ctx, const fbs_prog *prog, uint64_t *d_wires, siz
 // belongs to the context and is shared by all of its programs (it only ever grows).
 static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *chunk) {
     const size_t ctw = ctx->D + 1;
-    const size_t per_sample = (size_t)prog->n_slots * ctw * 8 + (size_t)std::max(1u, prog->max_sources) * (ctx->p.n + 1) * 4;
+    const size_t per_sample = (size_t)prog->n_slots * ctw * 8 + (size_t)std::max(1u, prog->max_sources) * (ctx->p.n + 1) * 4 +
+                              (size_t)prog->max_shared * 2 * ctx->N * 8;
     size_t free_b = 0, total_b = 0;
     FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4;
+    size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4 + ctx->acc_capacity * 2 * ctx->N * 8;
     // test hook: FBS_WIRE_BUDGET_MB caps what the wire slots may take, so that the chunked path runs at small sizes
     if (const char *cap = getenv("FBS_WIRE_BUDGET_MB")) have = std::min<size_t>(have, (size_t)std::max(1, atoi(cap)) << 20);
     const size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / per_sample));
@@ -787,6 +884,7 @@ static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *c
     }
     int rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_sources) * Tc);
     if (rc != FBS_OK) return rc;
+    if (prog->max_shared && (rc = ensure_acc(ctx, (size_t)prog->max_shared * Tc)) != FBS_OK) return rc;
     *chunk = Tc;
     return FBS_OK;
 }

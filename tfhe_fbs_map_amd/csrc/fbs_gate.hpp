@@ -27,4 +27,14 @@ __device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t i, uint
     return gv.out_base + (slot * gv.T + s) * ct_words;
 }
 
+// fused programs: the scratch row a rotation of TV_0 leaves its whole accumulator in, or null for an ordinary gate
+__device__ __forceinline__ uint64_t *gate_acc(const GateView &gv, size_t i, uint32_t N) {
+    if (!gv.acc_rows) return nullptr;
+    const size_t f = gv.f_begin + i;
+    const size_t g = f / gv.s_count, s = f % gv.s_count;
+    const uint32_t d = gv.dst_slot[g];
+    if (!(d & 0x80000000u)) return nullptr;
+    return gv.acc_rows + ((size_t)(d & 0x7FFFFFFFu) * gv.s_count + s) * 2 * N;
+}
+
 }  // namespace fbs

@@ -228,6 +228,50 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
 }
 
 // ---------------------------------------------------------------------------------------------
+// Several tables on one blind rotation (multi-value bootstrap; Carpov, Izabachene, Mollimard, CT-RSA 2019).  The test
+// vector above is delta_half * G(X) with G_j = +-(2 f - c), and (1 + X + .. + X^(N-1)) (1 - X) = 2 in Z[X]/(X^N + 1), so
+//     TV_F = TV_0 * D_F,   TV_0 = delta_half (1 + X + .. + X^(N-1)),   D_F = G (1 - X) / 2
+// -- an integer polynomial (every G_j has the parity of c) that is non-zero only where the table changes value: at box
+// boundaries j with f(x_j) != f(x_j - 1), and where the last half box flips to -(2 f(0) - c).  The coefficient at j = 0,
+// G_0 + G_(N-1), is zero by that very flip.
+// ---------------------------------------------------------------------------------------------
+int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint32_t *pos, int32_t *val, uint32_t *count,
+                       uint64_t *norm2, uint64_t *abs_sum) {
+    const uint32_t p = ctx->p.p_msg, N = ctx->N;
+    if (len == 0 || len > 2 * p) return FBS_E_TABLE;
+    int64_t c = 0;
+    if (len > p) {
+        c = (int64_t)table[0] + table[p];
+        for (uint32_t i = 0; i + p < len; i++)
+            if ((int64_t)table[i] + table[i + p] != c) return FBS_E_TABLE;
+    }
+    auto g_of = [&](uint32_t j) -> int64_t {
+        const uint64_t x = ((uint64_t)j * 2 * p + N) / (2ull * N);
+        const int64_t f = x < p ? (x < len ? table[x] : 0) : table[0];
+        return x < p ? 2 * f - c : -(2 * f - c);
+    };
+    uint32_t n = 0;
+    uint64_t n2 = 0, sum = 0;
+    int64_t prev = -g_of(N - 1);   // G_(-1) = -G_(N-1)
+    for (uint32_t j = 0; j < N; j++) {
+        const int64_t g = g_of(j);
+        const int64_t d = (g - prev) / 2;
+        prev = g;
+        if (d == 0) continue;
+        if (n > p || d > INT32_MAX || d < INT32_MIN) return FBS_E_TABLE;   // (cannot happen: p boxes, p + 1 boundaries)
+        pos[n] = j;
+        val[n] = (int32_t)d;
+        n++;
+        n2 += (uint64_t)(d * d);
+        sum += (uint64_t)(d < 0 ? -d : d);
+    }
+    *count = n;
+    *norm2 = n2;
+    *abs_sum = sum;
+    return FBS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // twiddles for the merged negacyclic NTT: fwd[i] = psi^bitrev(i), inv[i] = psi^-bitrev(i), psi = 7^((q-1)/2N)
 // (any primitive 2N-th root gives the same ciphertexts: the transform is an internal representation).
 // Entries [N, 2N) repeat the two half-size subtrees (nodes 2 and 3 of the twiddle tree) as tables of their own, N/2

@@ -36,6 +36,10 @@ struct GateView {
     // emits several tables per linear combination): source_of[g] = index of gate g's source in src_slot, null = g.
     const uint32_t *source_of;  // [n_gates] or null
     uint64_t *out_rows;         // non-null: bootstrap f writes row (f - f_begin) of this contiguous array instead of its slot
+    // Several tables on ONE blind rotation (fused programs, fbs_program_load_ex): a gate whose dst_slot has bit 31 set is
+    // the rotation of the table-independent test vector TV_0 for a source that several tables read; it leaves its whole
+    // accumulator in row (dst & 0x7fffffff) * s_count + sample of acc_rows ([row][2][N]) for k_multi_extract.
+    uint64_t *acc_rows;
     size_t T;                   // samples per wire in the buffers (stride)
     size_t s_begin, s_count;    // sample window of the launch
     size_t f_begin, count;      // bootstraps of this launch (flattened gate-major over the window)
@@ -84,6 +88,8 @@ struct fbs_ctx {
     uint64_t *d_psi_pow = nullptr;    // [N] psi^x, centred doubles: what the transforms of the monomials X^e - 1 are made from (group 2)
     uint32_t *d_ms = nullptr;        // scratch: mod-switched small ciphertexts [capacity][n+1]
     size_t ms_capacity = 0;
+    uint64_t *d_acc = nullptr;       // scratch: whole accumulators [capacity][2][N] of rotations several tables share
+    size_t acc_capacity = 0;         // in rows
     uint32_t *d_idx = nullptr;       // scratch for index arrays of the host-index wires API
     size_t idx_capacity = 0;
     uint64_t *d_wires = nullptr;     // wire slots of fbs_eval, shared by every program of the context
@@ -100,9 +106,16 @@ struct fbs_ctx {
 struct fbs_tvset {
     fbs_ctx *ctx = nullptr;
     uint32_t n_tables = 0;
-    uint64_t *d_tvs = nullptr;        // [n_tables][N]
-    uint64_t *d_post = nullptr;       // [n_tables]
+    uint64_t *d_tvs = nullptr;        // [n_tables + 1][N]: the tables, then TV_0 = delta_half (1 + X + .. + X^(N-1))
+    uint64_t *d_post = nullptr;       // [n_tables + 1]
     std::vector<uint64_t> post;       // host copy
+    // TV_F = TV_0 * D_F (host_build_tv_diff): the non-zero coefficients of the small integer polynomial D_F per table
+    uint32_t diff_cap = 0;            // entries per table in the two arrays below
+    uint32_t *d_diff_pos = nullptr;   // [n_tables][diff_cap]
+    int32_t *d_diff_val = nullptr;    // [n_tables][diff_cap]
+    uint32_t *d_diff_n = nullptr;     // [n_tables]
+    std::vector<uint64_t> diff_norm2; // |D_F|^2: what fusing multiplies the output noise variance by
+    std::vector<uint8_t> fusable;     // 0: the coefficients of D_F are too large for the 64-bit sums of k_multi_extract
 };
 
 namespace fbs {
@@ -120,6 +133,10 @@ void host_keygen(fbs_ctx *ctx);
 void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts);
 void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);
 int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64_t *tv, uint64_t *post_add);
+// D_F with TV_F = TV_0 * D_F as (position, value) pairs of its non-zero coefficients, at most p + 1 of them (`pos`, `val`
+// sized for that); *norm2 = |D_F|^2, *abs_sum = sum |d|.  Errors as host_build_tv.
+int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint32_t *pos, int32_t *val, uint32_t *count,
+                       uint64_t *norm2, uint64_t *abs_sum);
 void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv);
 
 // device side (fbs_kernels.hip); all asynchronous on `stream`
@@ -137,6 +154,11 @@ int dev_scatter_rows(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, 
 // rows of `count` ciphertexts: out[i] = wires[slot][s_begin + i] (slot >= 0) or the trivial ciphertext of `body`
 int dev_copy_out(fbs_ctx *ctx, const uint64_t *d_wires, size_t T, size_t s_begin, size_t count, int64_t slot, uint64_t body,
                  uint64_t *d_out, hipStream_t stream);
+// out[slot x_dst[e]][s] = SampleExtract_0(acc_rows[x_row[e] * s_count + s - s_begin] * D_table) + post, for the n_extract
+// tables e that share rotations of TV_0, samples [s_begin, s_begin + s_count)
+int dev_multi_extract(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_acc_rows, uint64_t *d_wires, size_t T, size_t s_begin,
+                      size_t s_count, uint32_t n_extract, const uint32_t *d_x_row, const uint32_t *d_x_table,
+                      const uint32_t *d_x_dst, hipStream_t stream);
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream);
 
 // profiling helpers
