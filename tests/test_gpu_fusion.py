@@ -189,3 +189,67 @@ def test_fused_samples_in_chunks(nat, toy_params, monkeypatch):
     assert np.array_equal(prog2.eval(cts, T), ref)
     for k, name in enumerate(low["out_names"]):
         assert np.array_equal(ctx2.decrypt(ref[k]), expect[name])
+
+
+def test_noise_of_a_shared_rotation_is_the_table_norm_times_an_ordinary_one(nat):
+    """Output noise variance of a table cut out of a shared rotation = |D_F|^2 x that of an ordinary bootstrap (what
+    `fusion_stats` / `choose_params` carry).  Measured on 4096 bootstraps per table at the reduced-noise benchmark set."""
+    from tfhe_fbs_map_amd import P1024
+    prm = P1024.replace(p_msg=7, n=64)                 # (short rotation: the ratio does not depend on n)
+    text = "m1 = 1 * a + 2 * b\nm2 = Bootstrap(m1, [0, 1, 1, 0])\nm3 = Bootstrap(m1, [0, 1, 0, 1])\nOutput x = m2\nOutput y = m3\n"
+    T = 4096
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 2, (2, T))
+    o = orc.Oracle(prm, seed=6)
+    delta = 2 * o.delta_half
+    var = {}
+    for fuse in (False, True):
+        ctx, low, tv, prog = load(nat, prm, text, ["a", "b"], fuse=fuse)
+        out = prog.eval(ctx.encrypt(bits, nonce0=1), T)
+        msgs = ctx.decrypt(out)
+        ph = o.phase(out).astype(np.int64)
+        err = (ph - msgs * delta + orc.Q // 2) % orc.Q - orc.Q // 2
+        var[fuse] = (err.astype(np.float64) ** 2).mean(axis=1)
+        v = bits[0] + 2 * bits[1]
+        assert np.array_equal(msgs[0], np.array([0, 1, 1, 0])[v]) and np.array_equal(msgs[1], np.array([0, 1, 0, 1])[v])
+    norms = [tv.fusion_norm2(low["tables"].index(t)) for t in ([0, 1, 1, 0], [0, 1, 0, 1])]
+    assert norms == [2, 4]
+    for k in range(2):
+        ratio = var[True][k] / var[False][k]
+        assert 0.8 * norms[k] < ratio < 1.25 * norms[k], (k, ratio, norms[k])
+
+
+BASIC = ["adder8__basic_p2", "2_input_gates__basic_p2", "half_adder__basic_p2", "full_adder__basic_p2", "aes_sbox__basic_p2", "trivium_iter_v2__basic_p2"]
+
+
+@pytest.mark.parametrize("name", BASIC)
+def test_default_config_fuses_where_it_pays_and_decrypts_to_the_reference(name):
+    """`LutExecEnv.eval` with the default ExecConfig: 128-bit parameters chosen for the FUSED noise statistic, shared
+    rotations where the program has any; every output of every harness sample equals the reference's cleartext."""
+    from tfhe_fbs_map_amd import ExecConfig, parse_fbs, security_bits
+    from tfhe_fbs_map_amd.params import margin_sigmas
+    try:
+        rec = load_fixture(name)
+    except FileNotFoundError:
+        pytest.skip("no such fixture")
+    T = 200
+    ins, expect = subsample(rec, T)
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+    cfg = ExecConfig(seed=5)
+    got = env.eval(ins, config=cfg)
+    for k, v in expect.items():
+        assert np.array_equal(np.asarray(got[k]).reshape(-1), np.asarray(v).reshape(-1)), k
+    (prog, _), = cfg._programs.values()
+    stats = env.stats()
+    p = prog.ctx.params.p_msg
+    fstats = env.fusion_stats(p)
+    assert prog.fused == (fstats["nb_rotation"] < stats["nb_bootstrap"])
+    assert prog.n_rotations == fstats["nb_rotation"] and prog.n_bootstrap == stats["nb_bootstrap"]
+    assert security_bits(prog.ctx.params) >= 127.9
+    assert margin_sigmas(prog.ctx.params, fstats["norm2_linprod"] if prog.fused else stats["norm2_linprod"]) >= 5.9
+    off = ExecConfig(seed=5, fuse_tables=False)                          # the switch: same plaintexts, every table its own rotation
+    got2 = env.eval(ins, config=off)
+    for k, v in expect.items():
+        assert np.array_equal(np.asarray(got2[k]).reshape(-1), np.asarray(v).reshape(-1)), k
+    (prog2, _), = off._programs.values()
+    assert not prog2.fused and prog2.n_rotations == stats["nb_bootstrap"]

@@ -145,3 +145,62 @@ def test_two_key_bits_per_step_every_table_mode(toy_params, l, beta):
     assert np.array_equal(o.decrypt(out), np.concatenate([np.array(t) for t in tables]))
     with pytest.raises(ValueError):
         orc.Oracle(prm.replace(n=prm.n + 1), seed=5)            # pairs need an even n
+
+
+# ---- several tables on one blind rotation (multi-value bootstrap) -----------------------------------
+TABLES_ALL_MODES = [
+    [0, 1, 1, 0, 1, 0, 0],
+    [0, 1, 2, 3, 2, 1, 0],
+    [0, 1],
+    [0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1],          # c = 1
+    [0, 0, 0, 1, 1, 0, 1, 0, 0, 0],                      # c = 0
+    [1, 1, 1, 0, 0, 1, 0, 1, 1, 1],                      # c = 2
+    [0, 1, 2, 3, 4, 5, 6, 2, 1, 0, -1, -2, -3, -4],      # c = 2, multi-valued, negative entries
+]
+
+
+@pytest.mark.parametrize("table", TABLES_ALL_MODES)
+def test_every_test_vector_is_tv0_times_a_small_integer_polynomial(toy, table):
+    """TV_F = TV_0 * D_F in Z_q[X]/(X^N + 1) with TV_0 = delta_half (1 + X + .. + X^(N-1)): the identity the shared rotation
+    rests on; D_F is zero except at box boundaries, and the facade's closed form for |D_F|^2 is its squared norm."""
+    from tfhe_fbs_map_amd.fbs_exec_env import table_fusion_norm2
+    tv, post = toy.build_tv(table)
+    d, post_d = toy.build_tv_diff(table)
+    assert post == post_d
+    assert np.count_nonzero(d) <= toy.p["p_msg"] and d[0] == 0
+    assert np.array_equal(orc.polymul_schoolbook(toy.tv0(), np.array([int(x) % orc.Q for x in d], np.uint64)), tv)
+    assert table_fusion_norm2(table, toy.p["p_msg"]) == int((d.astype(np.int64) ** 2).sum())
+
+
+def test_tables_cut_out_of_one_rotation_are_table_lookups(toy):
+    """All seven tables on one rotation per ciphertext, every message of the torus: f(m) where the table defines it,
+    c - f(m - p) on the other half (c = 0 for a table that stops at p)."""
+    p = toy.p["p_msg"]
+    msgs = np.arange(2 * p)
+    out = toy.bootstrap_multi(toy.encrypt(msgs, 300), TABLES_ALL_MODES)
+    for table, res in zip(TABLES_ALL_MODES, out):
+        c = table[0] + table[p] if len(table) > p else 0
+        got = toy.decrypt(res)
+        for m in range(2 * p):
+            if m < len(table):
+                assert got[m] == table[m] % (2 * p), (table, m)
+            elif m >= p and m - p < len(table):
+                assert got[m] == (c - table[m - p]) % (2 * p), (table, m)
+
+
+@pytest.mark.parametrize("name,T", [("adder8__basic_p2", 3), ("2_input_gates__basic_p2", 8), ("half_adder__basic_p2", 8),
+                                    ("adder8__search_p7", 2)])
+def test_fused_program_matches_reference_golden(toy_params, name, T):
+    """Decrypted-level pin of the fused evaluation: programs whose shared sources are rotated once decrypt to the reference's
+    cleartext goldens."""
+    rec = load_fixture(name)
+    ops, outs = lut_oracle.read_fbs(rec["fbs"])
+    tables = [op[3] for op in ops if op[0] == "boot"]
+    p = max(7, max(len(t) for t in tables))
+    o = orc.Oracle(toy_params.replace(log_n_poly=9, p_msg=p), seed=3)
+    ins, expect = subsample(rec, T)
+    cts = {k: o.encrypt(v, nonce0=1000 * i) for i, (k, v) in enumerate(ins.items())}
+    wires = oracle_eval_program(o, ops, outs, cts, fuse=True)
+    for out_name, src in outs:
+        if src not in ("0", "1"):
+            assert np.array_equal(o.decrypt(wires[src]), expect[out_name]), out_name

@@ -58,6 +58,18 @@ def min_fbs_size(tables, at_least=2):
     return p
 
 
+def table_fusion_norm2(table, p):
+    """|D_F|^2 for `table` at plaintext modulus p: the factor by which sharing a blind rotation with other tables
+    multiplies the noise variance of this table's output (include/fbs_exec.h, FBS_LOAD_FUSE_TABLES).  D_F is non-zero
+    where the table changes value between neighbouring boxes, and where the last half box flips to c - f(0)."""
+    assert table_is_valid(table, p)
+    L = len(table)
+    c = table[0] + table[p] if L > p else 0
+    f = [int(table[x]) if x < L else 0 for x in range(p)]
+    steps = [f[x] - f[x - 1] for x in range(1, p)] + [c - f[0] - f[p - 1]]
+    return sum(d * d for d in steps)
+
+
 # --------------------------------------------------------------------------------------------
 # execution configuration (no counterpart in the reference)
 # --------------------------------------------------------------------------------------------
@@ -77,6 +89,11 @@ class ExecConfig:
     min_margin: float = 6.0               # p_error ~ 2e-9 per bootstrap (the reference's optimizer default is 4 sigma)
     security: int = 128
     reduced_noise: bool = False           # params=None: the reduced-noise benchmark set for p (params.params_for) -- NOT secure
+    # Several tables on one linear combination (the reference's one-gate-one-bootstrap lowering, map_to_fbs.py:41-45): share
+    # ONE blind rotation per source (FBS_LOAD_FUSE_TABLES).  None = when it is cheaper: the shared outputs carry |D_F|^2
+    # times the noise variance, so the parameter set is chosen for the program's FUSED norm and its cost times the rotations
+    # left is compared with the unfused choice.  With explicit `params` None means off (their margin is the caller's).
+    fuse_tables: bool | None = None
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)
@@ -87,34 +104,54 @@ class ExecConfig:
             self.seed = int.from_bytes(os.urandom(8), "little")
         return self.seed
 
-    def context_for(self, p, norm2=1):
-        from . import _native as nat
+    def params_choice(self, p, norm2=1):
+        """The parameter set a program with plaintext modulus p and noise statistic norm2 is evaluated with."""
         from .params import REFERENCE_MARGIN, choose_params, params_for
         if self.params is None and self.reduced_noise:
-            prm = params_for(p)
-        elif self.params is None:
-            prm = choose_params(p, norm2, min_margin=self.min_margin, security=self.security,
-                                floor_margin=min(self.min_margin, REFERENCE_MARGIN))
-        else:
-            prm = self.params.replace(p_msg=p)
+            return params_for(p)
+        if self.params is None:
+            return choose_params(p, norm2, min_margin=self.min_margin, security=self.security,
+                                 floor_margin=min(self.min_margin, REFERENCE_MARGIN))
+        return self.params.replace(p_msg=p)
+
+    def context_of(self, prm):
+        from . import _native as nat
         key = (prm, self.key_seed(), self.device)
         ctx = self._contexts.get(key)
         if ctx is None:
             ctx = self._contexts[key] = nat.Context(prm, seed=self.key_seed(), device=self.device)
         return ctx
 
-    def program_for(self, ctx, low):
+    def context_for(self, p, norm2=1):
+        return self.context_of(self.params_choice(p, norm2))
+
+    def choose(self, env, p):
+        """(context, fuse) for a program: the parameter set of `params_choice` at the program's norm, and whether the
+        tables of shared sources share their blind rotation (`fuse_tables`)."""
+        from .params import bootstrap_cost
+        stats = env.stats()
+        fstats = env.fusion_stats(p) if self.fuse_tables is not False else None
+        if fstats is None or fstats["nb_rotation"] == stats["nb_bootstrap"] or (self.fuse_tables is None and self.params is not None):
+            return self.context_for(p, stats["norm2_linprod"]), False
+        fused = self.params_choice(p, fstats["norm2_linprod"])
+        if self.fuse_tables is True:
+            return self.context_of(fused), True
+        plain = self.params_choice(p, stats["norm2_linprod"])
+        cheaper = bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]
+        return (self.context_of(fused), True) if cheaper else (self.context_of(plain), False)
+
+    def program_for(self, ctx, low, fuse=False):
         """The loaded (device-resident) form of a lowered program, cached; the cache is bounded because every entry
         pins index tables in HBM (the wire buffer itself belongs to the context and is shared)."""
         from . import _native as nat
-        key = (id(ctx), id(low))
+        key = (id(ctx), id(low), bool(fuse))
         hit = self._programs.get(key)
         if hit is not None and hit[1] is low:
             self._programs.move_to_end(key)
             return hit[0]
         tv = ctx.tvset(low["tables"])
         prog = nat.Program(ctx, tv, len(low["input_names"]), low["kind"], low["arg0"], low["arg1"], low["const_coef"],
-                           low["term_coef"], low["term_src"], low["out_wire"])
+                           low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fuse)
         self._programs[key] = (prog, low)
         while len(self._programs) > max(1, self.max_programs):
             _, (old, _) = self._programs.popitem(last=False)
@@ -318,6 +355,27 @@ class LutExecEnv:
         return dict(nb_inp=count["inp"], nb_linprod=count["lin"], nb_bootstrap=count["boot"], max_lut_size=widest,
                     norm2_linprod=max(norm2.values()), nb_out=len(self.outputs))
 
+    def fusion_stats(self, p):
+        """What sharing blind rotations does to this program at plaintext modulus p (no counterpart in the reference):
+        nb_rotation = blind rotations left when every wire that several Bootstraps read is rotated once, and
+        norm2_linprod = the reference's statistic (`stats`) with the output of a shared rotation weighted by the |D_F|^2
+        of its table instead of 1 -- what the parameter choice of a fused evaluation has to carry."""
+        readers = {}
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Bootstrap):
+                readers[instr.val.name] = readers.get(instr.val.name, 0) + 1
+        norm2, rotations = {}, 0
+        for instr in self.instructions:
+            if isinstance(instr, LutExecEnv.Input):
+                norm2[instr.name] = 1
+            elif isinstance(instr, LutExecEnv.LinearProd):
+                norm2[instr.name] = sum(c * c * norm2[v.name] for c, v in instr.coef_vals)
+            else:
+                shared = readers[instr.val.name] >= 2
+                norm2[instr.name] = max(1, table_fusion_norm2(instr.table, p)) if shared else 1
+        rotations = sum(1 for n in readers.values() if n >= 2) + sum(n for n in readers.values() if n == 1)
+        return dict(nb_rotation=rotations, norm2_linprod=max(norm2.values(), default=1))
+
     def tables(self):
         return [i.table for i in self.instructions if isinstance(i, LutExecEnv.Bootstrap)]
 
@@ -392,7 +450,7 @@ class LutExecEnv:
         p = cfg.fbs_size or min_fbs_size(low["tables"])
         for t in low["tables"]:
             assert table_is_valid(t, p), "table %s cannot be evaluated by one bootstrap at fbs_size %d" % (t, p)
-        ctx = cfg.context_for(p, self.stats()["norm2_linprod"])
+        ctx, fuse = cfg.choose(self, p)
 
         names = low["input_names"]
         cols = [np.asarray(input_values[n]).reshape(-1) for n in names]
@@ -400,7 +458,7 @@ class LutExecEnv:
         bits = np.stack([np.broadcast_to(c, (T,)) for c in cols]).astype(np.int64) if cols else np.zeros((0, T), np.int64)
         assert bits.size == 0 or (bits.min() >= 0 and bits.max() <= 1), "inputs are bits"
 
-        program = cfg.program_for(ctx, low)
+        program = cfg.program_for(ctx, low, fuse)
         cts = ctx.encrypt(bits, nonce0=cfg.take_nonces(bits.size))
         out = ctx.decrypt(program.eval(cts, T))
         result = {}
