@@ -165,14 +165,18 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset
  * CSE merges identical tables only, fbs_exec_env.py:93-100).  A source wire that two or more Bootstraps read is rotated
  * ONCE, from the table-independent test vector TV_0 = Delta/2 (1 + X + .. + X^(N-1)); each table F is then cut out of that
  * accumulator by a product with the small integer polynomial D_F (TV_F = TV_0 * D_F; multi-value bootstrap, Carpov,
- * Izabachene, Mollimard, CT-RSA 2019) and a sample extraction.  Same decrypted results; the noise variance of such an
- * output is |D_F|^2 times that of an ordinary bootstrap (fbs_table_fusion_norm2: the caller's parameter choice must carry
- * it), and the ciphertexts differ from the unfused program's.  Levels of a fused program run whole (fbs_eval,
+ * Izabachene, Mollimard, CT-RSA 2019) and a sample extraction.  Same decrypted results; such an output carries more noise
+ * than an ordinary bootstrap's (fbs_table_fusion_norms: the caller's parameter choice must carry it), and the ciphertexts
+ * differ from the unfused program's.  Levels of a fused program run whole (fbs_eval,
  * fbs_eval_dev, fbs_level_bootstrap_dev over the full range without d_rows); slicing one across GPUs is refused. */
 #define FBS_LOAD_FUSE_TABLES 1u
 int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset *tv, uint32_t flags, fbs_prog **out);
-/* |D_F|^2 of table `table` of the set: the factor by which sharing a rotation multiplies its output noise variance */
-int fbs_table_fusion_norm2(const fbs_tvset *tv, uint32_t table, uint64_t *norm2);
+/* What sharing a rotation does to the noise of table `table`'s output, with TV_F = Delta/2 G_F(X) (G_j = +-(2 f - c)):
+ * *d_norm2 = |D_F|^2, *g_norm2 = |G_F|^2 (sums over the N coefficients).  The part of the blind-rotation noise that comes
+ * from the bootstrapping key's noise has independent coefficients and grows by |D_F|^2; the part that comes from rounding
+ * the accumulator is seen through the BINARY key S, whose mean 1/2 makes S D_F = G_F / 2 + (centred part) D_F: it grows
+ * by |D_F|^2 / 2 + |G_F|^2 / (2N).  max of the two bounds the variance factor for any mix. */
+int fbs_table_fusion_norms(const fbs_tvset *tv, uint32_t table, uint64_t *d_norm2, uint64_t *g_norm2);
 void fbs_program_destroy(fbs_prog *prog);
 /* depth (number of bootstrap levels) and the widest level, as scheduled */
 int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap);

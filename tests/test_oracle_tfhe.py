@@ -162,14 +162,20 @@ TABLES_ALL_MODES = [
 @pytest.mark.parametrize("table", TABLES_ALL_MODES)
 def test_every_test_vector_is_tv0_times_a_small_integer_polynomial(toy, table):
     """TV_F = TV_0 * D_F in Z_q[X]/(X^N + 1) with TV_0 = delta_half (1 + X + .. + X^(N-1)): the identity the shared rotation
-    rests on; D_F is zero except at box boundaries, and the facade's closed form for |D_F|^2 is its squared norm."""
-    from tfhe_fbs_map_amd.fbs_exec_env import table_fusion_norm2
+    rests on; D_F is zero except at box boundaries; the facade's closed forms for |D_F|^2 and the mean of G_F^2 (TV_F =
+    delta_half G_F) are those of the polynomials."""
+    from tfhe_fbs_map_amd.fbs_exec_env import table_fusion_norms
     tv, post = toy.build_tv(table)
     d, post_d = toy.build_tv_diff(table)
     assert post == post_d
     assert np.count_nonzero(d) <= toy.p["p_msg"] and d[0] == 0
     assert np.array_equal(orc.polymul_schoolbook(toy.tv0(), np.array([int(x) % orc.Q for x in d], np.uint64)), tv)
-    assert table_fusion_norm2(table, toy.p["p_msg"]) == int((d.astype(np.int64) ** 2).sum())
+    d2, g2_mean = table_fusion_norms(table, toy.p["p_msg"])
+    assert d2 == int((d.astype(np.int64) ** 2).sum())
+    centred = np.where(tv > orc.Q // 2, tv.astype(np.int64) - orc.Q, tv.astype(np.int64))
+    g = centred // toy.delta_half
+    assert np.array_equal(g * toy.delta_half, centred)
+    assert abs(float((g ** 2).mean()) - g2_mean) <= 2.0 * float((g ** 2).max()) * toy.p["p_msg"] / toy.N   # boxes are N/p wide, rounded
 
 
 def test_tables_cut_out_of_one_rotation_are_table_lookups(toy):

@@ -145,7 +145,7 @@ def _load():
         "fbs_bootstrap_wires_dev": (i32, [vp, vp, vp, sz, u32, vp, vp, vp, sz, sz, vp]),
         "fbs_program_load": (i32, [vp, C.POINTER(_ProgramDesc), vp, C.POINTER(vp)]),
         "fbs_program_load_ex": (i32, [vp, C.POINTER(_ProgramDesc), vp, u32, C.POINTER(vp)]),
-        "fbs_table_fusion_norm2": (i32, [vp, u32, C.POINTER(u64)]),
+        "fbs_table_fusion_norms": (i32, [vp, u32, C.POINTER(u64), C.POINTER(u64)]),
         "fbs_program_destroy": (None, [vp]),
         "fbs_program_info": (i32, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "fbs_eval": (i32, [vp, vp, vp, sz, vp]),
@@ -178,7 +178,7 @@ EXPORTED_SYMBOLS = (
     "fbs_poly_size_check", "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
-    "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_load_ex", "fbs_table_fusion_norm2", "fbs_program_destroy",
+    "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_load_ex", "fbs_table_fusion_norms", "fbs_program_destroy",
     "fbs_program_info",
     "fbs_searcher_create", "fbs_searcher_destroy", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms",
     "fbs_search_lincomb_coefs", "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
@@ -207,11 +207,12 @@ class TvSet:
         ctx._check(lib.fbs_tvset_create(ctx._h, _ptr(vals), _ptr(off), len(self.tables), C.byref(h)))
         self._h = h
 
-    def fusion_norm2(self, table):
-        """|D_F|^2 of table `table`: what sharing a blind rotation multiplies its output noise variance by."""
-        out = C.c_uint64()
-        self.ctx._check(lib.fbs_table_fusion_norm2(self._h, table, C.byref(out)))
-        return out.value
+    def fusion_norms(self, table):
+        """(|D_F|^2, |G_F|^2) of table `table` (include/fbs_exec.h, fbs_table_fusion_norms): what sharing a blind rotation
+        does to its output noise."""
+        d, g = C.c_uint64(), C.c_uint64()
+        self.ctx._check(lib.fbs_table_fusion_norms(self._h, table, C.byref(d), C.byref(g)))
+        return d.value, g.value
 
     def __del__(self):
         if getattr(self, "_h", None) and self.ctx._h and lib is not None:

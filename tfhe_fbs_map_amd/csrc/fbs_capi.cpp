@@ -291,6 +291,7 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
     std::vector<uint32_t> dpos((size_t)std::max(1u, n_tables) * tv->diff_cap, 0), dn(std::max(1u, n_tables), 0);
     std::vector<int32_t> dval((size_t)std::max(1u, n_tables) * tv->diff_cap, 0);
     tv->diff_norm2.assign(n_tables, 0);
+    tv->g_norm2.assign(n_tables, 0);
     tv->fusable.assign(n_tables, 0);
     for (uint32_t t = 0; t < n_tables; t++) {
         if (table_off[t + 1] < table_off[t]) return set_error(ctx, FBS_E_INVALID, "table offsets must be non-decreasing");
@@ -300,7 +301,7 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
         uint64_t abs_sum = 0;
         if (rc == FBS_OK)
             rc = host_build_tv_diff(ctx, vals, len, dpos.data() + (size_t)t * tv->diff_cap, dval.data() + (size_t)t * tv->diff_cap, &dn[t],
-                                    &tv->diff_norm2[t], &abs_sum);
+                                    &tv->diff_norm2[t], &tv->g_norm2[t], &abs_sum);
         if (rc != FBS_OK)
             return set_error(ctx, rc, "table " + std::to_string(t) + " of length " + std::to_string(len) +
                                           " is not evaluable by one bootstrap at p = " + std::to_string(ctx->p.p_msg));
@@ -325,9 +326,10 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
     return FBS_OK;
 }
 
-int fbs_table_fusion_norm2(const fbs_tvset *tv, uint32_t table, uint64_t *norm2) {
-    if (!tv || !norm2 || table >= tv->n_tables) return FBS_E_INVALID;
-    *norm2 = tv->diff_norm2[table];
+int fbs_table_fusion_norms(const fbs_tvset *tv, uint32_t table, uint64_t *d_norm2, uint64_t *g_norm2) {
+    if (!tv || table >= tv->n_tables) return FBS_E_INVALID;
+    if (d_norm2) *d_norm2 = tv->diff_norm2[table];
+    if (g_norm2) *g_norm2 = tv->g_norm2[table];
     return FBS_OK;
 }
 

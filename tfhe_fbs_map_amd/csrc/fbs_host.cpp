@@ -236,7 +236,7 @@ int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64
 // G_0 + G_(N-1), is zero by that very flip.
 // ---------------------------------------------------------------------------------------------
 int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint32_t *pos, int32_t *val, uint32_t *count,
-                       uint64_t *norm2, uint64_t *abs_sum) {
+                       uint64_t *norm2, uint64_t *g_norm2, uint64_t *abs_sum) {
     const uint32_t p = ctx->p.p_msg, N = ctx->N;
     if (len == 0 || len > 2 * p) return FBS_E_TABLE;
     int64_t c = 0;
@@ -251,10 +251,11 @@ int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, u
         return x < p ? 2 * f - c : -(2 * f - c);
     };
     uint32_t n = 0;
-    uint64_t n2 = 0, sum = 0;
+    uint64_t n2 = 0, g2 = 0, sum = 0;
     int64_t prev = -g_of(N - 1);   // G_(-1) = -G_(N-1)
     for (uint32_t j = 0; j < N; j++) {
         const int64_t g = g_of(j);
+        g2 += (uint64_t)(g * g);
         const int64_t d = (g - prev) / 2;
         prev = g;
         if (d == 0) continue;
@@ -267,6 +268,7 @@ int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, u
     }
     *count = n;
     *norm2 = n2;
+    *g_norm2 = g2;
     *abs_sum = sum;
     return FBS_OK;
 }

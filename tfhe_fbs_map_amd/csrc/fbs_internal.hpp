@@ -114,7 +114,8 @@ struct fbs_tvset {
     uint32_t *d_diff_pos = nullptr;   // [n_tables][diff_cap]
     int32_t *d_diff_val = nullptr;    // [n_tables][diff_cap]
     uint32_t *d_diff_n = nullptr;     // [n_tables]
-    std::vector<uint64_t> diff_norm2; // |D_F|^2: what fusing multiplies the output noise variance by
+    std::vector<uint64_t> diff_norm2; // |D_F|^2 and |G_F|^2 (TV_F = delta_half G_F): what fusing does to the output noise
+    std::vector<uint64_t> g_norm2;    //   (fbs_table_fusion_norms)
     std::vector<uint8_t> fusable;     // 0: the coefficients of D_F are too large for the 64-bit sums of k_multi_extract
 };
 
@@ -134,9 +135,9 @@ void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_
 void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);
 int host_build_tv(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint64_t *tv, uint64_t *post_add);
 // D_F with TV_F = TV_0 * D_F as (position, value) pairs of its non-zero coefficients, at most p + 1 of them (`pos`, `val`
-// sized for that); *norm2 = |D_F|^2, *abs_sum = sum |d|.  Errors as host_build_tv.
+// sized for that); *norm2 = |D_F|^2, *g_norm2 = |G_F|^2 (TV_F = delta_half G_F), *abs_sum = sum |d|.  Errors as host_build_tv.
 int host_build_tv_diff(const fbs_ctx *ctx, const int32_t *table, uint32_t len, uint32_t *pos, int32_t *val, uint32_t *count,
-                       uint64_t *norm2, uint64_t *abs_sum);
+                       uint64_t *norm2, uint64_t *g_norm2, uint64_t *abs_sum);
 void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint64_t> &inv);
 
 // device side (fbs_kernels.hip); all asynchronous on `stream`

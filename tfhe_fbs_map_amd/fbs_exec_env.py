@@ -58,16 +58,25 @@ def min_fbs_size(tables, at_least=2):
     return p
 
 
-def table_fusion_norm2(table, p):
-    """|D_F|^2 for `table` at plaintext modulus p: the factor by which sharing a blind rotation with other tables
-    multiplies the noise variance of this table's output (include/fbs_exec.h, FBS_LOAD_FUSE_TABLES).  D_F is non-zero
-    where the table changes value between neighbouring boxes, and where the last half box flips to c - f(0)."""
+def table_fusion_norms(table, p):
+    """(|D_F|^2, mean of G_F^2) for `table` at plaintext modulus p, where TV_F = Delta/2 G_F(X) = TV_0 D_F (include/
+    fbs_exec.h, FBS_LOAD_FUSE_TABLES): D_F is non-zero where the table changes value between neighbouring boxes and where
+    the last half box flips to c - f(0); G_F is 2 f - c on every box."""
     assert table_is_valid(table, p)
     L = len(table)
     c = table[0] + table[p] if L > p else 0
     f = [int(table[x]) if x < L else 0 for x in range(p)]
     steps = [f[x] - f[x - 1] for x in range(1, p)] + [c - f[0] - f[p - 1]]
-    return sum(d * d for d in steps)
+    return sum(d * d for d in steps), sum((2 * v - c) ** 2 for v in f) / p
+
+
+def table_fusion_factor(table, p):
+    """Upper bound of the factor by which sharing a blind rotation multiplies the noise variance of this table's output.
+    Key-noise part of the rotation noise: independent coefficients, |D_F|^2.  Rounding part: seen through the binary key
+    S = 1/2 (1 + .. + X^(N-1)) + centred part, and (1 + .. + X^(N-1)) D_F = G_F, so it grows by |D_F|^2 / 2 + mean(G_F^2) / 2
+    (measured: tests/test_gpu_fusion.py).  The larger of the two holds for any mix."""
+    d2, g2 = table_fusion_norms(table, p)
+    return max(1.0, float(d2), d2 / 2.0 + g2 / 2.0)
 
 
 # --------------------------------------------------------------------------------------------
@@ -358,8 +367,8 @@ class LutExecEnv:
     def fusion_stats(self, p):
         """What sharing blind rotations does to this program at plaintext modulus p (no counterpart in the reference):
         nb_rotation = blind rotations left when every wire that several Bootstraps read is rotated once, and
-        norm2_linprod = the reference's statistic (`stats`) with the output of a shared rotation weighted by the |D_F|^2
-        of its table instead of 1 -- what the parameter choice of a fused evaluation has to carry."""
+        norm2_linprod = the reference's statistic (`stats`) with the output of a shared rotation weighted by its table's
+        `table_fusion_factor` instead of 1 -- what the parameter choice of a fused evaluation has to carry."""
         readers = {}
         for instr in self.instructions:
             if isinstance(instr, LutExecEnv.Bootstrap):
@@ -372,7 +381,7 @@ class LutExecEnv:
                 norm2[instr.name] = sum(c * c * norm2[v.name] for c, v in instr.coef_vals)
             else:
                 shared = readers[instr.val.name] >= 2
-                norm2[instr.name] = max(1, table_fusion_norm2(instr.table, p)) if shared else 1
+                norm2[instr.name] = table_fusion_factor(instr.table, p) if shared else 1
         rotations = sum(1 for n in readers.values() if n >= 2) + sum(n for n in readers.values() if n == 1)
         return dict(nb_rotation=rotations, norm2_linprod=max(norm2.values(), default=1))
 
