@@ -31,6 +31,11 @@
  *     of convention is committed together with a green run of tests/test_oracle_tfhe.py (decrypt == the reference's
  *     cleartext goldens, all table modes) -- a change that breaks decryption cannot hide behind GPU == oracle.
  *
+ *     Several tables on one blind rotation (orc_tv0 / orc_build_tv_diff / orc_multi_extract, round 2) restate the
+ *     multi-value bootstrap of Carpov, Izabachene, Mollimard (CT-RSA 2019, section 3) with schoolbook products; the
+ *     identity TV_F = TV_0 * D_F is checked as polynomial arithmetic and the decrypted results against the same goldens
+ *     (tests/test_oracle_tfhe.py).
+ *
  * All vectors are canonical residues in [0, q).
  */
 #ifndef TFHE_ORACLE_H
