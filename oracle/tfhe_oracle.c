@@ -579,9 +579,21 @@ void orc_keyswitch(const orc_ctx *c, const uint64_t *ct_big, uint64_t *ct_small)
     }
 }
 
+/* Mask words are rounded to the closest multiple of 2^46 / 2N (q treated as 2^46, as everywhere).  The rounding errors
+ * eps_i of the mask reach the phase as sum_i eps_i s_i through a BINARY key, whose bits have mean 1/2: the evaluator knows
+ * every eps_i, so it removes the expected value sum_i eps_i / 2 from the body before rounding it ("mean-compensated"
+ * modulus switch).  What is left is sum_i eps_i (s_i - 1/2): variance n/4 roundings instead of n/2
+ * (tfhe_fbs_map_amd/params.py, variances).  [NOT IN REFERENCE]; the halving floors. */
 void orc_modswitch(const orc_ctx *c, const uint64_t *ct_small, uint32_t *ms) {
-    uint32_t sh = ORC_QBITS - c->p.log_n_poly - 2, mask = 2 * c->N - 1;
-    for (uint32_t i = 0; i <= c->p.n; i++) ms[i] = (uint32_t)(((ct_small[i] >> sh) + 1) >> 1) & mask;
+    uint32_t sh = ORC_QBITS - c->p.log_n_poly - 1, mask = 2 * c->N - 1, n = c->p.n; /* sh = bits dropped */
+    int64_t eps = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t m = ((ct_small[i] >> (sh - 1)) + 1) >> 1;
+        eps += (int64_t)ct_small[i] - (int64_t)(m << sh); /* in [-2^(sh-1), 2^(sh-1)) */
+        ms[i] = (uint32_t)m & mask;
+    }
+    uint64_t body = gl_sub(ct_small[n], gl_from_i64(eps >> 1));
+    ms[n] = (uint32_t)(((body >> (sh - 1)) + 1) >> 1) & mask;
 }
 
 /* out = X^r * in  (r in [0,2N)) in Z_q[X]/(X^N+1) */

@@ -210,3 +210,26 @@ def test_fused_program_matches_reference_golden(toy_params, name, T):
     for out_name, src in outs:
         if src not in ("0", "1"):
             assert np.array_equal(o.decrypt(wires[src]), expect[out_name]), out_name
+
+
+def test_modulus_switch_is_mean_compensated():
+    """The n mask roundings reach the phase through a binary key; their expected value sum eps_i / 2 is taken off the body
+    before it is rounded, which leaves (1 + n/4) / 12 of variance (in units of the 2N grid) where a plain switch leaves
+    (1 + n/2) / 12 -- the term `params.variances` carries, and what moves p = 31 from N = 4096 to N = 2048."""
+    from tfhe_fbs_map_amd import Params
+    n, N = 512, 256
+    o = orc.Oracle(Params(n=n, log_n_poly=8, p_msg=4, sigma_lwe=4, sigma_glwe=4), seed=2)
+    s = o.keys()["sk_lwe"].astype(object)
+    rng = np.random.default_rng(0)
+    T = 400
+    errs = np.empty(T)
+    for i, ct in enumerate(o.encrypt(rng.integers(0, 8, T), nonce0=7)):
+        small = o.keyswitch(ct)
+        ms = o.modswitch(small)
+        exact = (int(small[n]) - sum(int(a) for a, bit in zip(small[:n], s) if bit)) % orc.Q * (2 * N) / orc.Q
+        got = (int(ms[n]) - sum(int(a) for a, bit in zip(ms[:n], s) if bit)) % (2 * N)
+        errs[i] = (got - exact + N) % (2 * N) - N
+    var = float((errs ** 2).mean())
+    assert abs(errs.mean()) < 0.5
+    assert 0.8 * (1 + n / 4) / 12 < var < 1.2 * (1 + n / 4) / 12, var
+    assert var < 0.65 * (1 + n / 2) / 12

@@ -34,7 +34,7 @@ def test_default_params_are_secure_and_the_benchmark_set_says_it_is_not():
     assert margin_sigmas(d.replace(p_msg=15), norm2=1) < 2
     assert margin_sigmas(d.replace(p_msg=2), norm2=1) > 6
     # p = 31 does not fit N = 1024 (modulus switch alone) and is sent to N = 2048
-    assert margin_sigmas(P1024.replace(p_msg=31), norm2=1) < 4.5
+    assert margin_sigmas(P1024.replace(p_msg=31), norm2=1) < 5.0           # (4.5 sigma even with the mean-compensated modulus switch)
     assert params_for(31).log_n_poly == 11 and params_for(15).log_n_poly == 10
     assert margin_sigmas(params_for(31), norm2=325) > 5
 
@@ -63,17 +63,21 @@ def test_selector_moves_n_and_N():
     small, big = choose_params(2, 1), choose_params(15, 281)
     assert small.N == 1024 and big.N == 2048 and big.n > small.n
     assert choose_params(15, 281).n != choose_params(15, 281, min_margin=4.0).n
-    # p = 31 at norm2 = 325: the modulus switch at N = 2048 leaves 5.9 sigma, so 6 sigma takes N = 4096 ...
-    with pytest.raises(ValueError):
-        choose_params(31, 325, poly_sizes=(9, 10, 11))
+    # p = 31 at norm2 = 325: with the mean-compensated modulus switch (variance (1 + n/4) roundings instead of (1 + n/2))
+    # N = 2048 carries it at 6 sigma; without it the switch alone left 5.9 and the selector had to take N = 4096 at more than
+    # twice the cost.  N = 1024 cannot.
     big = choose_params(31, 325)
-    assert big.N == 4096 and margin_sigmas(big, 325) >= 6.0 and security_bits(big) >= 127.9
-    # ... or a margin relaxed towards the reference's own 4 sigma at N = 2048, at half the cost
-    c = choose_params(31, 325, poly_sizes=(9, 10, 11), floor_margin=REFERENCE_MARGIN)
-    assert c.N == 2048 and margin_sigmas(c, 325) >= 5.0 and security_bits(c) >= 127.9
-    assert bootstrap_cost(c) < 0.6 * bootstrap_cost(big)
+    assert big.N == 2048 and margin_sigmas(big, 325) >= 6.0 and security_bits(big) >= 127.9
     with pytest.raises(ValueError):
-        choose_params(63, 100)                                   # beyond N = 4096
+        choose_params(31, 325, poly_sizes=(9, 10))
+    # a margin relaxed towards the reference's own 4 sigma is never dearer
+    c = choose_params(31, 325, floor_margin=REFERENCE_MARGIN, min_margin=REFERENCE_MARGIN)
+    assert c.N == 2048 and margin_sigmas(c, 325) >= 4.0 and bootstrap_cost(c) <= bootstrap_cost(big)
+    # p = 63 takes N = 4096; p = 127 is beyond it
+    huge = choose_params(63, 100)
+    assert huge.N == 4096 and margin_sigmas(huge, 100) >= 6.0 and bootstrap_cost(huge) > 2 * bootstrap_cost(big)
+    with pytest.raises(ValueError):
+        choose_params(127, 10)
 
 
 def test_cost_ranking_against_the_references_points():

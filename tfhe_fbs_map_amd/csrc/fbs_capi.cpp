@@ -84,10 +84,17 @@ static hipStream_t pick(fbs_ctx *ctx, void *stream) { return stream ? (hipStream
 static int ensure_ms(fbs_ctx *ctx, size_t count) {
     if (count <= ctx->ms_capacity) return FBS_OK;
     if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // kernels may still read the old buffer
-    if (ctx->d_ms) (void)hipFree(ctx->d_ms);
+    for (void *p : {(void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body})
+        if (p) (void)hipFree(p);
     ctx->d_ms = nullptr;
+    ctx->d_ms_eps = nullptr;
+    ctx->d_ms_body = nullptr;
     ctx->ms_capacity = 0;
     FBS_HIP(ctx, hipMalloc(&ctx->d_ms, count * (ctx->p.n + 1) * sizeof(uint32_t)));
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ms_eps, count * 8));
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ms_body, count * 8));
+    FBS_HIP(ctx, hipMemset(ctx->d_ms_eps, 0, count * 8));   // every launch leaves it zero again (k_ms_body)
+    FBS_HIP(ctx, hipDeviceSynchronize());
     ctx->ms_capacity = count;
     return FBS_OK;
 }
@@ -211,7 +218,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_acc,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);

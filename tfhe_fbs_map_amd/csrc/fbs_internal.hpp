@@ -88,6 +88,8 @@ struct fbs_ctx {
     uint64_t *d_psi_pow = nullptr;    // [N] psi^x, centred doubles: what the transforms of the monomials X^e - 1 are made from (group 2)
     uint32_t *d_ms = nullptr;        // scratch: mod-switched small ciphertexts [capacity][n+1]
     size_t ms_capacity = 0;
+    unsigned long long *d_ms_eps = nullptr;   // [capacity] sums of the mask words' rounding errors (zero between launches)
+    uint64_t *d_ms_body = nullptr;            // [capacity] bodies before their rounding (mean-compensated modulus switch)
     uint64_t *d_acc = nullptr;       // scratch: whole accumulators [capacity][2][N] of rotations several tables share
     size_t acc_capacity = 0;         // in rows
     uint32_t *d_idx = nullptr;       // scratch for index arrays of the host-index wires API

@@ -33,6 +33,12 @@ struct KsArgs {
     const uint64_t *ksk;   // [D*t][stride]
     const uint64_t *corr;  // [stride]  (B/2) * sum of all key rows, mod q
     uint32_t *ms;          // [count][n+1]
+    // Mean-compensated modulus switch: the rounding errors eps_i of the n mask words reach the phase as sum eps_i s_i
+    // through a BINARY key (mean 1/2), and the evaluator knows them: every kernel adds what its columns left into eps[f],
+    // parks the unrounded body in body_raw[f], and k_ms_body rounds body - (sum eps) / 2 (and clears eps[f] for the next
+    // launch).  The phase error left is sum eps_i (s_i - 1/2): n/4 roundings of variance instead of n/2.
+    unsigned long long *eps;   // [count]  two's complement sums, zero on entry
+    uint64_t *body_raw;        // [count]
     uint32_t offs;         // B/2 at every digit position
     uint32_t n, D, t, gamma, stride, ct_words, log2_2n;
     uint32_t cols_major;   // 1: blockIdx.x walks the column blocks (see dev_keyswitch), 0: the ciphertext tiles
@@ -44,9 +50,33 @@ struct KsArgs {
 __device__ __forceinline__ uint32_t ks_round(uint64_t w, uint32_t tg, uint32_t offs) {
     return (uint32_t)(((w >> (FQ_BITS - 1 - tg)) + 1) >> 1) + offs;
 }
-__device__ __forceinline__ uint32_t ks_finish(uint64_t acc, uint64_t body, uint64_t corr, uint32_t log2_2n) {
-    const uint64_t r = fq_add(fq_sub(body, acc % FQ), corr);
-    return (uint32_t)(((r >> (FQ_BITS - log2_2n - 1)) + 1) >> 1) & ((1u << log2_2n) - 1u);
+__device__ __forceinline__ uint64_t ks_finish(uint64_t acc, uint64_t body, uint64_t corr) {
+    return fq_add(fq_sub(body, acc % FQ), corr);
+}
+// One word r of the switched ciphertext to [0, 2N) (q treated as 2^46).  Mask words (col < n): rounded, stored, the
+// rounding error added to *eps.  The body (col == n) is parked unrounded for k_ms_body.
+__device__ __forceinline__ void ms_store(const KsArgs &a, size_t f, uint32_t col, uint64_t r, int64_t *eps) {
+    if (col == a.n) {
+        a.body_raw[f] = r;
+        return;
+    }
+    const uint32_t sh = FQ_BITS - a.log2_2n;   // bits dropped
+    const uint64_t m = ((r >> (sh - 1)) + 1) >> 1;
+    *eps += (int64_t)r - (int64_t)(m << sh);
+    a.ms[f * (a.n + 1) + col] = (uint32_t)m & ((1u << a.log2_2n) - 1u);
+}
+__device__ __forceinline__ void ms_flush(const KsArgs &a, size_t f, int64_t eps) {
+    if (eps) atomicAdd(a.eps + f, (unsigned long long)eps);
+}
+__global__ __launch_bounds__(256) void k_ms_body(uint32_t *ms, unsigned long long *eps, const uint64_t *body_raw, uint32_t n,
+                                                 uint32_t log2_2n, size_t count) {
+    const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= count) return;
+    const int64_t e = (int64_t)eps[f];
+    eps[f] = 0;
+    const uint64_t body = fq_sub(body_raw[f], fq_from_i64(e >> 1));   // (the halving floors)
+    const uint32_t sh = FQ_BITS - log2_2n;
+    ms[f * (n + 1) + n] = (uint32_t)(((body >> (sh - 1)) + 1) >> 1) & ((1u << log2_2n) - 1u);
 }
 
 // Small batches: workgroup = FB ciphertexts x 256 output columns; lanes are columns, the key row is read once
@@ -89,7 +119,9 @@ __global__ __launch_bounds__(256) void k_keyswitch(KsArgs a) {
     for (int f = 0; f < FB; f++) {
         if (f0 + f >= a.count) break;
         const uint64_t body = col == a.n ? ct_ptr[f][a.D] : 0;
-        a.ms[(f0 + f) * (a.n + 1) + col] = ks_finish(acc[f], body, a.corr[col], a.log2_2n);
+        int64_t eps = 0;
+        ms_store(a, f0 + f, col, ks_finish(acc[f], body, a.corr[col]), &eps);
+        ms_flush(a, f0 + f, eps);
     }
 }
 
@@ -209,12 +241,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_lanes(KsArgs a) {
         const size_t f = f0 + lane + 64 * u;
         if (f >= a.count) continue;
         const uint64_t body = ct_ptr[lane + 64 * u][a.D];
+        int64_t eps = 0;
 #pragma unroll
         for (int c = 0; c < COLS; c++) {
             const uint32_t col = col0 + c;
             if (col > a.n) break;
-            a.ms[f * (a.n + 1) + col] = ks_finish(sum[u][c], col == a.n ? body : 0, a.corr[col], a.log2_2n);
+            ms_store(a, f, col, ks_finish(sum[u][c], col == a.n ? body : 0, a.corr[col]), &eps);
         }
+        ms_flush(a, f, eps);
     }
 }
 
@@ -322,15 +356,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const dou
         const size_t f = f0 + lane + 64 * u;
         if (f >= a.count) continue;
         const uint64_t body = ct_ptr[lane + 64 * u][a.D];
+        int64_t eps = 0;
 #pragma unroll
         for (int c = 0; c < COLS; c++) {
             const uint32_t col = col0 + c;
             if (col > a.n) break;
             // out = body - sum: the sum is signed here, so no correction vector
             const uint64_t sum = fp_to_u64(fp_canon(acc[u][c]));
-            const uint64_t r = fq_sub(col == a.n ? body : 0, sum);
-            a.ms[f * (a.n + 1) + col] = (uint32_t)(((r >> (FQ_BITS - a.log2_2n - 1)) + 1) >> 1) & ((1u << a.log2_2n) - 1u);
+            ms_store(a, f, col, fq_sub(col == a.n ? body : 0, sum), &eps);
         }
+        ms_flush(a, f, eps);
     }
 }
 
@@ -456,6 +491,8 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     a.ksk = ctx->d_ksk;
     a.corr = ctx->d_ks_corr;
     a.ms = d_ms;
+    a.eps = ctx->d_ms_eps;
+    a.body_raw = ctx->d_ms_body;
     for (uint32_t v = 0; v < p.t_ksk; v++) a.offs |= (1u << (p.gamma_ksk - 1)) << (v * p.gamma_ksk);
     a.n = p.n;
     a.D = ctx->D;
@@ -518,6 +555,8 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         ctx->prof.kernel[0] = "k_keyswitch<8>";
         hipLaunchKernelGGL(k_keyswitch<FB>, grid, dim3(256), shmem, stream, a);
     }
+    hipLaunchKernelGGL(k_ms_body, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, stream, d_ms, a.eps, a.body_raw, p.n,
+                       a.log2_2n, a.count);
     prof_end(ctx, 0, stream, e0, e1);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;

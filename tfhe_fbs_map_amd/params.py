@@ -94,7 +94,9 @@ def variances(prm: Params):
     # key switch: kN t balanced digits in [-2^g/2, 2^g/2) against key noise, plus the rounding to t*gamma bits
     # seen through a binary key
     v_ks = k * N * (t * (b2 * b2 + 2) / 12.0 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
-    v_ms = (1 + n / 2.0) / (12.0 * (2.0 * N) ** 2)
+    # modulus switch, mean-compensated (k_ms_body, fbs_kernels.hip): the body's own rounding, and the n mask roundings seen through
+    # s_i - 1/2 (variance 1/4) because the expected value sum eps_i / 2 is taken off the body before it is rounded
+    v_ms = (1 + n / 4.0) / (12.0 * (2.0 * N) ** 2)
     return v_br, v_ks, v_ms
 
 
@@ -180,7 +182,7 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     for log_n in poly_sizes:
         N = 1 << log_n
         s_glwe = (sigma_min(k * N, security) if security is not None else (sigma if sigma is not None else REDUCED_SIGMA)) / q
-        v_ms = (1 + ns / 2.0) / (12.0 * (2.0 * N) ** 2)
+        v_ms = (1 + ns / 4.0) / (12.0 * (2.0 * N) ** 2)
         if (v_ms >= need).all():
             continue
         for (l, beta), group in [((l_, b_), g_) for (l_, b_) in _GADGETS for g_ in groups]:
