@@ -28,7 +28,10 @@ for name in fixture_names():
     ok = set(got) == set(expect) and all(
         (int(got[k]) == int(v)) if isinstance(v, int) else np.array_equal(np.asarray(got[k]).reshape(-1), v) for k, v in expect.items())
     st = env.stats()
-    rows.append(dict(name=name, ok=bool(ok), nb_bootstrap=st["nb_bootstrap"], norm2=st["norm2_linprod"], seconds=round(time.time() - t0, 2)))
+    prog = next(reversed(cfg._programs.values()))[0] if cfg._programs else None      # the program this eval loaded or reused
+    rows.append(dict(name=name, ok=bool(ok), nb_bootstrap=st["nb_bootstrap"], norm2=st["norm2_linprod"], seconds=round(time.time() - t0, 2),
+                     shared_rotations=bool(prog and prog.fused), rotations=prog.n_rotations if prog else None,
+                     N=prog.ctx.params.N if prog else None))
     if not ok:
         bad.append((name, "wrong output"))
     if len(cfg._contexts) > 6:                     # keys are large: keep a few contexts
@@ -38,6 +41,8 @@ for name in fixture_names():
     print("%-44s %s  %5d FBS  norm2 %4d  %.1fs" % (name, "ok " if ok else "BAD", st["nb_bootstrap"], st["norm2_linprod"], time.time() - t0), flush=True)
 sets = {}
 summary = dict(samples=T, fixtures=len(rows), all_ok=not bad, failures=bad, bootstraps=sum(r["nb_bootstrap"] for r in rows) * T,
+               rotations=sum((r["rotations"] or 0) for r in rows) * T, programs_with_shared_rotations=sum(r["shared_rotations"] for r in rows),
+               poly_sizes=sorted({r["N"] for r in rows if r["N"]}),
                seconds=round(time.time() - t_all, 1), rows=rows)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(summary, open("gpurun_out/secure_all_fixtures.json", "w"), indent=1)
