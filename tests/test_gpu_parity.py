@@ -400,3 +400,37 @@ def test_n4096_gadget_shapes_bit_exact(nat, toy_params, l, beta, t, gamma):
     ref, _ = o.bootstrap_batch(cts, MODES, ids)
     assert np.array_equal(got, ref)
     assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(tb) for tb in MODES]))
+
+
+@pytest.mark.parametrize("n,log_n,l,beta,t,gamma,group", [
+    (630, 10, 3, 7, 8, 2, 1),       # the benchmark shape: 79 column blocks, 256 k-steps
+    (778, 11, 1, 21, 16, 1, 2),     # the 128-bit set of heavy-norm programs: one-bit digits, 16 levels
+    (500, 9, 2, 10, 3, 6, 1),       # wide digits
+    (77, 8, 2, 9, 5, 3, 1),         # fewer columns than one tile is wide
+])
+def test_matrix_core_key_switch_equals_the_integer_kernels(nat, n, log_n, l, beta, t, gamma, group):
+    """Batches above 64 key-switch as an int8 GEMM on the matrix cores (k_ks_gemm: balanced digits x balanced base-256 limbs of
+    the key, int32 sums, recombined mod q); smaller ones on the integer kernels, which the oracle tests pin word for word.
+    Same ciphertexts, so the same outputs: a batch of 203 (ragged against every tile size) against the same ciphertexts
+    in slices of 29."""
+    from tfhe_fbs_map_amd import Params
+    prm = Params(n=n, log_n_poly=log_n, l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=gamma, p_msg=7, sigma_lwe=1 << 10,
+                 sigma_glwe=1 << 4, bsk_group=group)
+    ctx = nat.Context(prm, seed=8)
+    rng = np.random.default_rng(n)
+    count = 203
+    tables = [[0, 1, 1, 0, 1, 0, 0], [0, 1, 2, 3, 2, 1, 0]]
+    tv = ctx.tvset(tables)
+    ids = rng.integers(0, 2, count).astype(np.uint32)
+    cts = ctx.encrypt(rng.integers(0, 7, count), nonce0=5)
+    cts[3, :-1] = rng.integers(0, orc.Q, prm.ct_words - 1, dtype=np.uint64)        # a ciphertext of nothing: every digit pattern
+    cts[4, :] = 0
+    cts[5, :] = orc.Q - 1
+    whole = ctx.bootstrap_batch(tv, cts, ids)
+    ctx.profile(True)
+    ctx.profile_read()
+    parts = np.concatenate([ctx.bootstrap_batch(tv, cts[i:i + 29], ids[i:i + 29]) for i in range(0, count, 29)])
+    assert "k_keyswitch" in ctx.profile_read()["keyswitch"]["kernel"]
+    ctx.bootstrap_batch(tv, cts, ids)
+    assert "k_ks_gemm" in ctx.profile_read()["keyswitch"]["kernel"]
+    assert np.array_equal(whole, parts)

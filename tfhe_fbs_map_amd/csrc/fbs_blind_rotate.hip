@@ -617,6 +617,7 @@ int dev_upload_keys(fbs_ctx *ctx) {
         FBS_HIP(ctx, hipMemcpy(ctx->d_ksk_f, kf.data(), kf.size() * 8, hipMemcpyHostToDevice));
     }
     FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));   // fwd_c / inv_c are about to go out of scope
+    if (int rc = dev_keyswitch_gemm_setup(ctx)) return rc;
     switch (p.log_n_poly) {
 #define X(L) case L: return upload_keys_t<L>(ctx);
         FBS_FOR_EACH_SHAPE(X)

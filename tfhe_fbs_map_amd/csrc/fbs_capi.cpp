@@ -218,7 +218,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_ks_a, (void *)ctx->d_ks_b, (void *)ctx->d_ks_c, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);

@@ -82,6 +82,10 @@ struct fbs_ctx {
     uint64_t *d_bsk_hat_small = nullptr;   // the same in the evaluation order of the small-launch shape (fbs_ntt.hpp), or null
     uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
     uint64_t *d_ksk_f = nullptr;     // the same key as centred doubles (bit patterns), for the FP64 key-switch kernel
+    int8_t *d_ks_b = nullptr;        // the key as balanced base-256 limbs in MFMA fragment order (k_ks_gemm, fbs_kernels.hip)
+    int8_t *d_ks_a = nullptr;        // scratch: digit fragments of one pass of ciphertexts
+    int *d_ks_c = nullptr;           // scratch: limb sums [rows][6][cols_pad], zero between launches
+    size_t ks_rows_capacity = 0;
     uint64_t *d_ks_corr = nullptr;   // [ksk_stride]  (B/2) * sum of all key-switching-key rows: balanced digits from unsigned fields
     uint64_t *d_tw_fwd = nullptr;    // [N]  psi^bitrev(i)
     uint64_t *d_tw_inv = nullptr;    // [N]  psi^-bitrev(i)
@@ -145,6 +149,7 @@ void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint6
 // device side (fbs_kernels.hip); all asynchronous on `stream`
 int dev_supported(const fbs_ctx *ctx);   // FBS_OK or error if no kernel instance for the params
 int dev_upload_keys(fbs_ctx *ctx);       // BSK -> NTT domain, KSK padded
+int dev_keyswitch_gemm_setup(fbs_ctx *ctx);   // limb fragments of the key-switching key for the int8 MFMA key switch
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream);
 int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream);
 // `T` = sample stride of the wire buffer, samples [s_begin, s_begin + s_count) are computed

@@ -370,6 +370,185 @@ __global__ __launch_bounds__(64 * WAVES) void k_keyswitch_fp(KsArgs a, const dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// The key switch as an int8 GEMM on the matrix cores (v_mfma_i32_32x32x32_i8, gfx950).
+//
+//     out[f][col] = body - sum_{j, v} digit_v(a_j of ciphertext f) * K[(j, v)][col]   (mod q)
+//
+// is a [ciphertexts] x [kN t] by [kN t] x [n + 1] product.  The balanced digits are tiny (|d| <= 2^(gamma-1)); a centred key
+// word (|K| < 2^45) is cut into SIX balanced base-256 limbs, K = sum_b limb_b 256^b with limb_b in [-128, 128), so that
+//     C[f][b][col] = sum_kappa digit[f][kappa] * limb_b[kappa][col]
+// is an int8 x int8 -> int32 GEMM with N = 6 (n + 1) columns, EXACT (|C| <= 2^(gamma-1) 2^7 kN t < 2^31, checked by the
+// launcher), and out = body - sum_b C_b 256^b mod q is recombined by the finishing kernel, which also does the modulus
+// switch.  Same integers as the other key-switch kernels, so the same ciphertexts.  Per 1024 bootstraps at P1024 this is
+// 6.4e10 int8 multiply-adds x 2 -- 13 us at the dense int8 rate -- where the FP64 form spends 8.3e7 wave-FMAs on the vector
+// pipe (0.47 ms measured); the key shrinks from 8 to 6 bytes per word.
+//
+// Operand fragments are stored the way a wave reads them: tile (32 rows or columns) x k-step (32 values of kappa) x lane x
+// 16 bytes, lane l = 32 h + r holding row/column r and the 16 values kappa = 32 ks + 16 h + i.  A and B use the SAME
+// assignment of (h, i) to kappa, which is all the instruction needs for a dot product over kappa.  kappa = v * kN + j
+// (digit-major), so that the 16 bytes one thread of the digit kernel stores are 16 consecutive mask words of one level.
+// ---------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct KsGemm {
+    uint32_t D, t, gamma, n, cols_pad;   // cols_pad: n + 1 rounded up to 64; the GEMM has 6 * cols_pad columns (limb-major)
+    uint32_t ksteps;                     // D * t / 32
+};
+
+// key -> limb fragments, once per key.  One thread per (kappa, column): six bytes, one per limb plane.
+__global__ __launch_bounds__(256) void k_ks_limbs(const uint64_t *ksk, uint32_t stride, KsGemm g, int8_t *B) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t col = (uint32_t)(idx % g.cols_pad);
+    const size_t kappa = idx / g.cols_pad;
+    if (kappa >= (size_t)g.D * g.t) return;
+    const uint32_t v = (uint32_t)(kappa / g.D), j = (uint32_t)(kappa % g.D);
+    int64_t x = 0;
+    if (col <= g.n) {
+        const uint64_t w = ksk[((size_t)j * g.t + v) * stride + col];
+        x = w > FQ / 2 ? (int64_t)w - (int64_t)FQ : (int64_t)w;   // centred
+    }
+    const uint32_t ks = (uint32_t)(kappa >> 5), h = (uint32_t)(kappa >> 4) & 1u, i = (uint32_t)kappa & 15u;
+    for (uint32_t b = 0; b < 6; b++) {
+        const int64_t limb = ((x + 128) & 255) - 128;   // balanced: in [-128, 128)
+        x = (x - limb) >> 8;
+        const uint32_t nn = b * g.cols_pad + col;
+        B[(((size_t)(nn >> 5) * g.ksteps + ks) * 64 + h * 32 + (nn & 31)) * 16 + i] = (int8_t)limb;
+    }
+}
+
+// ciphertexts -> digit fragments.  Workgroup = 32 ciphertexts x 8 blocks of 16 mask words; a thread rounds its 16 words and
+// stores one 16-byte fragment per level.  Rows past the batch are zero.
+__global__ __launch_bounds__(256) void k_ks_digits(KsArgs a, KsGemm g, size_t f0, size_t rows, int8_t *A) {
+    const uint32_t r = threadIdx.x & 31, wb = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const size_t m = (size_t)blockIdx.x * 32 + r;
+    if (wb * 16 >= g.D) return;
+    const uint32_t tg = g.t * g.gamma, dmask = (1u << g.gamma) - 1u, half = 1u << (g.gamma - 1);
+    uint32_t ab[16];
+    if (m < rows) {
+        const uint64_t *row = ks_in(a.gv, f0 + m, a.ct_words) + (size_t)wb * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i++) ab[i] = ks_round(row[i], tg, a.offs);
+    }
+    for (uint32_t v = 0; v < g.t; v++) {
+        const uint32_t sh = g.gamma * (g.t - 1 - v);
+        uint32_t packed[4] = {0, 0, 0, 0};
+        if (m < rows) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int d = (int)((ab[i] >> sh) & dmask) - (int)half;   // balanced digit
+                packed[i >> 2] |= ((uint32_t)d & 255u) << (8 * (i & 3));
+            }
+        }
+        const size_t kappa = (size_t)v * g.D + (size_t)wb * 16;
+        const uint32_t ks = (uint32_t)(kappa >> 5), h = (uint32_t)(kappa >> 4) & 1u;
+        uint4 *dst = reinterpret_cast<uint4 *>(A + (((size_t)blockIdx.x * g.ksteps + ks) * 64 + h * 32 + r) * 16);
+        *dst = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+    }
+}
+
+// C += A B over k-steps [blockIdx.z * klen, ...): four waves, 2 x 2, each MT x NT tiles of 32 x 32.  Fragments come straight
+// from global memory (16 bytes per lane, a kilobyte per wave and fragment, contiguous); both matrices are a few tens of MB
+// and live in L2 / Infinity Cache.  Partial sums of the k-slices meet in C through integer atomics.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void k_ks_gemm(const v4i *__restrict__ A, const v4i *__restrict__ B, int *__restrict__ C,
+                                                 uint32_t ksteps, uint32_t klen, uint32_t ldc) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t mt0 = (blockIdx.y * 2 + (wave >> 1)) * MT, nt0 = (blockIdx.x * 2 + (wave & 1)) * NT;
+    const uint32_t k0 = blockIdx.z * klen;
+    const uint32_t k1 = k0 + klen < ksteps ? k0 + klen : ksteps;
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0;
+    const v4i *pa[MT], *pb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) pa[i] = A + ((size_t)(mt0 + i) * ksteps + k0) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NT; j++) pb[j] = B + ((size_t)(nt0 + j) * ksteps + k0) * 64 + lane;
+    // a ring of three fragment sets: the loads of k-step k + 2 are in flight while the products of k-step k run (an L2 round
+    // trip is several times the 4 x 32 cycles the matrix pipe spends on one step)
+    const uint32_t steps = k1 - k0;
+    v4i fa[3][MT], fb[3][NT];
+    auto fetch = [&](int buf, uint32_t step) {
+        const size_t at = (size_t)(step < steps ? step : steps - 1) * 64;   // past the end: the last step again, unused
+#pragma unroll
+        for (int i = 0; i < MT; i++) fa[buf][i] = pa[i][at];
+#pragma unroll
+        for (int j = 0; j < NT; j++) fb[buf][j] = pb[j][at];
+    };
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+    for (uint32_t step = 0; step < steps; step += 3) {
+        fetch(2, step + 2);
+        multiply(0);
+        fetch(0, step + 3);
+        if (step + 1 < steps) multiply(1);
+        fetch(1, step + 4);
+        if (step + 2 < steps) multiply(2);
+    }
+    // C/D layout of the 32 x 32 forms: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const uint32_t row = (mt0 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = (nt0 + j) * 32 + (lane & 31);
+                atomicAdd(C + (size_t)row * ldc + col, acc[i][j][e]);
+            }
+}
+
+// limbs -> word mod q -> modulus switch.  A wave takes four ciphertext rows with its lanes on 64 consecutive columns
+// (coalesced reads of the six limb planes -- all 24 requested before the first is used -- and coalesced stores of the
+// switched words), adds the rounding errors of a row up across the lanes (one atomic per row and wave), and leaves the
+// part of C it read zero for the next launch.
+__global__ __launch_bounds__(256) void k_ks_gemm_finish(KsArgs a, KsGemm g, size_t f0, size_t rows, int *C, uint32_t ldc) {
+    constexpr int ROWS = 4;   // rows per wave
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t col = blockIdx.x * 64 + lane;
+    const size_t m0 = ((size_t)blockIdx.y * 4 + wave) * ROWS;
+    int limb[ROWS][6];
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+        const size_t m = m0 + i < rows ? m0 + i : rows - 1;
+        int *crow = C + m * ldc + col;
+#pragma unroll
+        for (int b = 0; b < 6; b++) limb[i][b] = col <= g.n ? crow[b * g.cols_pad] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+        const size_t m = m0 + i;
+        if (m >= rows) return;   // (wave-uniform)
+        const size_t f = f0 + m;
+        int64_t eps = 0;
+        if (col <= g.n) {
+            int *crow = C + m * ldc + col;
+#pragma unroll
+            for (int b = 0; b < 6; b++) crow[b * g.cols_pad] = 0;
+            const int64_t lo = (int64_t)limb[i][0] + ((int64_t)limb[i][1] << 8) + ((int64_t)limb[i][2] << 16);   // |.| < 2^48
+            const int64_t hi = (int64_t)limb[i][3] + ((int64_t)limb[i][4] << 8) + ((int64_t)limb[i][5] << 16);
+            const uint64_t sum = fq_add(fq_from_i64(lo), fq_mul(fq_from_i64(hi), 1ull << 24));
+            const uint64_t body = col == g.n ? ks_in(a.gv, f, a.ct_words)[g.D] : 0;
+            ms_store(a, f, col, fq_sub(body, sum), &eps);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) eps += __shfl_xor(eps, d);
+        if (lane == 0) ms_flush(a, f, eps);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // linear combination over wire slots: out = sum coef_i * wire_i + const (exact FP64 products, lazy sum)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lincomb(uint64_t *wires, size_t T, size_t s_begin, size_t s_count, uint32_t ct_words,
@@ -484,6 +663,69 @@ int dev_supported(const fbs_ctx *ctx) {
     return FBS_OK;
 }
 
+static KsGemm gemm_shape(const fbs_ctx *ctx) {
+    KsGemm g{};
+    g.D = ctx->D;
+    g.t = ctx->p.t_ksk;
+    g.gamma = ctx->p.gamma_ksk;
+    g.n = ctx->p.n;
+    g.cols_pad = (ctx->p.n + 1 + 63) / 64 * 64;
+    g.ksteps = ctx->D * ctx->p.t_ksk / 32;
+    return g;
+}
+
+// limb fragments of the key-switching key (after the integer copy d_ksk is in place)
+int dev_keyswitch_gemm_setup(fbs_ctx *ctx) {
+    const KsGemm g = gemm_shape(ctx);
+    const size_t bytes = (size_t)g.ksteps * 32 * 6 * g.cols_pad;
+    if (ctx->d_ks_b) (void)hipFree(ctx->d_ks_b);
+    ctx->d_ks_b = nullptr;
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ks_b, bytes));
+    const size_t threads = (size_t)g.D * g.t * g.cols_pad;
+    hipLaunchKernelGGL(k_ks_limbs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ksk, ctx->ksk_stride, g,
+                       ctx->d_ks_b);
+    FBS_HIP(ctx, hipGetLastError());
+    FBS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FBS_OK;
+}
+
+// digits -> GEMM -> recombination + modulus switch, in passes of at most 8192 ciphertexts (the scratch stays bounded)
+static int keyswitch_gemm(fbs_ctx *ctx, KsArgs &a, hipStream_t stream) {
+    const KsGemm g = gemm_shape(ctx);
+    constexpr size_t PASS = 8192;
+    const size_t want = std::min<size_t>(PASS, (a.count + 127) / 128 * 128);
+    const uint32_t ldc = 6 * g.cols_pad;
+    if (ctx->ks_rows_capacity < want) {
+        if (ctx->d_ks_a) (void)hipFree(ctx->d_ks_a);   // (hipFree waits for the kernels that may still use them)
+        if (ctx->d_ks_c) (void)hipFree(ctx->d_ks_c);
+        ctx->d_ks_a = nullptr;
+        ctx->d_ks_c = nullptr;
+        ctx->ks_rows_capacity = 0;
+        FBS_HIP(ctx, hipMalloc(&ctx->d_ks_a, want * (size_t)g.ksteps * 32));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_ks_c, want * (size_t)ldc * 4));
+        FBS_HIP(ctx, hipMemset(ctx->d_ks_c, 0, want * (size_t)ldc * 4));   // every launch leaves it zero again
+        FBS_HIP(ctx, hipDeviceSynchronize());
+        ctx->ks_rows_capacity = want;
+    }
+    ctx->prof.kernel[0] = "k_ks_gemm<2,2> (int8 MFMA)";
+    for (size_t f0 = 0; f0 < a.count; f0 += PASS) {
+        const size_t rows = std::min(PASS, a.count - f0);
+        const unsigned m_blocks = (unsigned)((rows + 127) / 128), n_blocks = ldc / 128;
+        hipLaunchKernelGGL(k_ks_digits, dim3(m_blocks * 4, (g.D / 16 + 7) / 8), dim3(256), 0, stream, a, g, f0, rows, ctx->d_ks_a);
+        // enough workgroups to keep every CU busy: the k range is cut where the (m, n) grid alone is too small
+        const unsigned want_split = (2u * (unsigned)ctx->cu_count + m_blocks * n_blocks - 1) / (m_blocks * n_blocks);
+        unsigned split = std::max(1u, std::min({want_split, 16u, g.ksteps / 16u}));
+        if (const char *e = getenv("FBS_KS_SPLIT")) split = std::max(1, atoi(e));   // (tuning)
+        const uint32_t klen = (g.ksteps + split - 1) / split;
+        hipLaunchKernelGGL((k_ks_gemm<2, 2>), dim3(n_blocks, m_blocks, (g.ksteps + klen - 1) / klen), dim3(256), 0, stream,
+                           reinterpret_cast<const v4i *>(ctx->d_ks_a), reinterpret_cast<const v4i *>(ctx->d_ks_b), ctx->d_ks_c, g.ksteps, klen,
+                           ldc);
+        hipLaunchKernelGGL(k_ks_gemm_finish, dim3(g.cols_pad / 64, (unsigned)((rows + 15) / 16)), dim3(256), 0, stream, a, g, f0, rows,
+                           ctx->d_ks_c, ldc);
+    }
+    return FBS_OK;
+}
+
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream) {
     const fbs_params &p = ctx->p;
     KsArgs a{};
@@ -522,7 +764,12 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         const double per_word = (double)p.t_ksk * std::ldexp(1.0, 44 + (int)p.gamma_ksk);
         const double room = std::ldexp(1.0, 53) - std::ldexp(1.0, 45);
         static const bool allow_fp = !(getenv("FBS_KS_INTEGER") && getenv("FBS_KS_INTEGER")[0] == '1');
-        if (a.count > 64 && cols_major && allow_fp && ctx->d_ksk_f && per_word <= room) {
+        // int8 GEMM on the matrix cores: exact while 2^(gamma-1) * 2^7 * kN t stays below 2^31
+        static const bool allow_gemm = !(getenv("FBS_KS_NO_MFMA") && getenv("FBS_KS_NO_MFMA")[0] == '1');
+        if (a.count > 64 && allow_gemm && ctx->d_ks_b && std::ldexp((double)ctx->D * p.t_ksk, (int)p.gamma_ksk + 6) < 2147483648.0) {
+            const int rc = keyswitch_gemm(ctx, a, stream);
+            if (rc != FBS_OK) return rc;
+        } else if (a.count > 64 && cols_major && allow_fp && ctx->d_ksk_f && per_word <= room) {
             const uint32_t words_per_fold = (uint32_t)std::min(1024.0, std::floor(room / per_word));
             const size_t tiles = (a.count + 127) / 128;
             for (size_t t0 = 0; t0 < tiles; t0 += 65535) {

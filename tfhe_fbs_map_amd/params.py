@@ -116,21 +116,26 @@ def p_error(margin: float) -> float:
 
 def bootstrap_cost(prm: Params) -> float:
     """Relative cost of one functional bootstrap, in the unit the kernels are bound by (FP64 instruction issue), with
-    the default P1024 shape = 1: n CMUX steps of (k+1)(l+1) transforms of N log N / 2 butterflies (8 instructions each)
-    plus (k+1)^2 l N exact products (7 each, accumulate included), and the kN t (n+1) multiply-adds of the key switch
-    weighted by their measured share (5 % of the P1024 step).  The reference ranks parameter sets by the optimizer's
-    `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
+    the default P1024 shape = 1.  Per CMUX step and coefficient, from the instruction counts of k_blind_rotate (DESIGN.md
+    section 5): (k+1)(l+1) transforms of log N / 2 butterflies of 8 instructions, (k+1)^2 l exact products of 7 (accumulate
+    included), 2 l for the digits and 12 for rotation, rounding and re-centring; times n steps, times what the multi-wave
+    transforms of N >= 2048 cost on top (measured: 1.11 at N = 2048, 1.15 at N = 4096).  Against measurements (profiles/r02/
+    selector_bench.jsonl): N = 1024 l = 2 0.77 modelled / 0.79 measured; N = 2048 l = 1 1.33 / 1.33; N = 2048 l = 2 2.16 /
+    2.13; N = 4096 l = 2 5.2 / 5.2.  The kN t (n+1) multiply-adds of the key switch are weighted by their measured share
+    (1.5 % of the P1024 step since it runs as an int8 GEMM on the matrix cores; 5 % before).  The reference ranks parameter
+    sets by the optimizer's `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
 
     def blind(n_, l_, N_, log_n):
-        return n_ * ((k + 1) * (l_ + 1) * N_ * log_n / 2.0 * 8.0 + (k + 1) ** 2 * l_ * N_ * 7.0)
+        per_coefficient = (k + 1) * ((l_ + 1) * 4.0 * log_n + 7.0 * (k + 1) * l_ + 2.0 * l_ + 12.0)
+        return n_ * N_ * per_coefficient * (1.15 if log_n >= 12 else 1.11 if log_n == 11 else 1.0)
 
     # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.72 with one
-    # gadget level (10.2 against 14.1 ms per 1024 bootstraps at N = 2048, n = 722 / 718).  With l levels the bundle costs
+    # gadget level (10.0 against 14.0 ms per 1024 bootstraps at N = 2048, n = 714 / 710).  With l levels the bundle costs
     # 6 l exact products per coefficient and pair of key bits where it saves l + 1 transforms: it does not pay beyond
     # l = 1 (P1024, l = 3: 13.5 against 10.8 ms)
     pairs = 1.0 if prm.bsk_group != 2 else (0.72 if l == 1 else 1.25)
-    return 0.95 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.05 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
+    return 0.985 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.015 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
 # ---- selector ------------------------------------------------------------------------------------------------------
