@@ -1,6 +1,9 @@
 // HIP kernels of libfbsexec.so other than the blind rotation (fbs_blind_rotate.hip), gfx950 only:
 //
-//   k_keyswitch_lanes / k_keyswitch   LWE key switch kN -> n fused with the modulus switch q -> 2N
+//   k_ks_digits / k_ks_gemm / k_ks_gemm_finish   LWE key switch kN -> n as an int8 GEMM on the matrix cores (batches > 64)
+//   k_keyswitch_fp / k_keyswitch_lanes / k_keyswitch   the same on the FP64 / integer vector pipes (fallback, small batches)
+//   k_ms_body                          the body word of the mean-compensated modulus switch q -> 2N
+//   k_multi_extract                    tables cut out of a shared blind rotation (fused programs)
 //   k_lincomb                         LinearProd over wire slots
 //
 // plus the profiling helpers and the launchers for those kernels.
