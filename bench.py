@@ -265,6 +265,7 @@ def run_batch(args, rank, world, local, dist):
     ctx.close()
     if world == 1 and not args.no_secure:
         result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
+        result["shared_rotations"] = shared_rotations_leg(local)
     return result
 
 
@@ -293,6 +294,56 @@ def secure_leg(B, local, steps):
     # reference's own Trivium / Kreyvium comparison point (experiments/analyse_results.py:317)
     small = choose_params(4, 2)
     rec["n1024_p4"] = dict(one(small), note="128-bit set for p = 4 at norm2 = 2: the N = 1024 kernels at a secure parameter set")
+    return rec
+
+
+def shared_rotations_leg(local, bits=32, T=512):
+    """Several tables on ONE blind rotation (include/fbs_exec.h FBS_LOAD_FUSE_TABLES): a ripple-carry adder built
+    gate by gate and lowered like the reference's MapToFBSBasic -- XOR and AND of the same pair of wires are two tables on
+    one linear combination (fbs_mapper/map_to_fbs.py:41-45) -- evaluated with and without shared rotations, each at the
+    128-bit parameter set chosen for its own noise statistic; every sum is decrypted and checked."""
+    import numpy as np
+    from tfhe_fbs_map_amd import ExecConfig
+    from tfhe_fbs_map_amd.fbs_exec_env import min_fbs_size
+    from tfhe_fbs_map_amd.netlist import BitExecEnv, map_basic
+    from tfhe_fbs_map_amd.params import margin_sigmas
+    env = BitExecEnv()
+    a = [env.input("a%d" % i) for i in range(bits)]
+    b = [env.input("b%d" % i) for i in range(bits)]
+    carry = None
+    for i in range(bits):
+        x, g = env.op_xor(a[i], b[i]), env.op_and(a[i], b[i])
+        s_i, carry = (x, g) if carry is None else (env.op_xor(x, carry), env.op_or(g, env.op_and(x, carry)))
+        env.output("s%d" % i, s_i)
+    env.output("cout", carry)
+    lut = map_basic(env)
+    low = lut.lower()
+    p = min_fbs_size(low["tables"])
+    rng = np.random.default_rng(3)
+    x, y = rng.integers(0, 2, (bits, T)), rng.integers(0, 2, (bits, T))
+    ins = {("a%d" % i): x[i] for i in range(bits)} | {("b%d" % i): y[i] for i in range(bits)}
+    want = sum((x[i].astype(object) + y[i].astype(object)) << i for i in range(bits))
+    rec = dict(circuit="%d-bit ripple-carry adder, one table per two-input gate" % bits, samples=T, p=p,
+               norm2=lut.stats()["norm2_linprod"], norm2_with_shared_rotations=round(lut.fusion_stats(p)["norm2_linprod"], 2))
+    for fuse in (False, True):
+        cfg = ExecConfig(seed=9, fuse_tables=fuse, device=local)
+        ctx, fused = cfg.choose(lut, p)
+        prog = cfg.program_for(ctx, low, fused)
+        cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]).astype(np.int64), nonce0=1)
+        prog.eval(cts[:, :8].copy(), 8)
+        t0 = time.perf_counter()
+        res = prog.eval(cts, T)
+        dt = time.perf_counter() - t0
+        dec = ctx.decrypt(res)
+        got = sum(dec[low["out_names"].index("s%d" % i)].astype(object) << i for i in range(bits))
+        got = got + (dec[low["out_names"].index("cout")].astype(object) << bits)
+        norm2 = rec["norm2_with_shared_rotations"] if fused else rec["norm2"]
+        rec["fused" if fuse else "plain"] = dict(
+            seconds=round(dt, 4), tables=prog.n_bootstrap, blind_rotations=prog.n_rotations,
+            tables_per_s=round(prog.n_bootstrap * T / dt), params=params_record(ctx.params),
+            margin_sigmas_at_its_norm2=round(margin_sigmas(ctx.params, norm2), 2), all_sums_correct=bool(all(g == w for g, w in zip(got, want))))
+        ctx.close()
+    rec["speedup"] = round(rec["plain"]["seconds"] / rec["fused"]["seconds"], 3)
     return rec
 
 

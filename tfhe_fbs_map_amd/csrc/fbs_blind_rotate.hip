@@ -83,6 +83,8 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 //   3  also beta <= 7: the first butterfly stage of the forward transforms is two exact FMAs (first_butterfly, fbs_ntt.hpp)
 //   4  l = 1 (one wide digit, any beta: the shape the 128-bit parameter sets take at N = 2048): as 1, without the loop
 //      over further levels -- and without the registers the compiler keeps alive for it
+//   5, 6, 7  l = 2 (the 128-bit sets for p <= 4 at N = 1024 and for p = 31, 63): as 1, 2, 3 with the two levels written out
+//      (no spills at N = 1024 where the loop form spills 21 registers, 13 instead of 27 at N = 2048)
 // FPW: bootstraps per workgroup.  The hardware deals the waves of a workgroup round the four SIMDs of a CU but starts
 // every workgroup at the same SIMD often enough that two-wave workgroups pile up on two SIMDs while the other two
 // idle whenever a CU holds fewer than four of them (measured: 512 bootstraps took 9.7 ms, 256 took 5.7 ms); four-wave
@@ -90,14 +92,14 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 template <int LOGN, int LL, int DIG, int FPW>
 __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = typename NttFor<LOGN, LL>::type;
-    constexpr int FIRST = DIG == 3 ? 2 : DIG == 2 ? 1 : 0;
+    constexpr int FIRST = (DIG == 3 || DIG == 7) ? 2 : (DIG == 2 || DIG == 6) ? 1 : 0;
     constexpr bool BOUNDED = DIG >= 1;
-    constexpr bool ONE_LEVEL = DIG == 4;
+    constexpr bool ONE_LEVEL = DIG == 4, TWO_LEVELS = DIG >= 5;
 #ifndef FBS_PEEL_MAX_LL
 #define FBS_PEEL_MAX_LL 6   // measured: peeling costs the two-waves-per-polynomial shapes more in spills than it saves
 #endif
     // first level peeled off the loop (it assigns the sums instead of adding to zeros): pays where registers allow
-    constexpr bool PEEL = ONE_LEVEL || LL <= FBS_PEEL_MAX_LL;
+    constexpr bool PEEL = ONE_LEVEL || TWO_LEVELS || LL <= FBS_PEEL_MAX_LL;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds_all[FPW * 2 * 2 * N];   // [bootstrap][component][ping-pong][N]
     const uint32_t sub = threadIdx.x >> (LL + 1);          // which bootstrap of the workgroup
@@ -241,7 +243,10 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 other[2 * j + 1] = ASSIGN ? p1 : other[2 * j + 1] + p1;
             }
         };
-        if constexpr (PEEL) {
+        if constexpr (TWO_LEVELS) {
+            level(1, std::true_type{});
+            level(0, std::false_type{});
+        } else if constexpr (PEEL) {
             level((int)a.l - 1, std::true_type{});
             if constexpr (!ONE_LEVEL)
                 for (int lv = (int)a.l - 2; lv >= 0; lv--) level(lv, std::false_type{});
@@ -680,7 +685,8 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         FBS_HIP(ctx, hipGetLastError());
         return FBS_OK;
     }
-    const int dig = p.l_bsk > 5 ? 0 : p.l_bsk == 1 ? 4 : p.beta_bsk <= 7 ? 3 : p.beta_bsk <= 9 ? 2 : 1;
+    const int by_beta = p.beta_bsk <= 7 ? 3 : p.beta_bsk <= 9 ? 2 : 1;
+    const int dig = p.l_bsk > 5 ? 0 : p.l_bsk == 1 ? 4 : p.l_bsk == 2 ? 4 + by_beta : by_beta;
     // at most one bootstrap per CU: the shape with twice the waves per bootstrap, where there is one (fbs_ntt.hpp)
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
@@ -694,6 +700,9 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
 #define LAUNCH_DIG(L, LL_, FPW)                                                                                        \
     do {                                                                                                               \
         if (dig == 4) LAUNCH_LL(L, LL_, 4, FPW);                                                                       \
+        else if (dig == 5) LAUNCH_LL(L, LL_, 5, FPW);                                                                  \
+        else if (dig == 6) LAUNCH_LL(L, LL_, 6, FPW);                                                                  \
+        else if (dig == 7) LAUNCH_LL(L, LL_, 7, FPW);                                                                  \
         else if (dig == 3) LAUNCH_LL(L, LL_, 3, FPW);                                                                  \
         else if (dig == 2) LAUNCH_LL(L, LL_, 2, FPW);                                                                  \
         else if (dig == 1) LAUNCH_LL(L, LL_, 1, FPW);                                                                  \
