@@ -26,7 +26,7 @@
  *     balanced digits with carries in both the blind rotation and the key switch, Delta = 2*round(q/4p), the test-vector
  *     box boundaries round(j*p/N) -- this file and the GPU kernels were specified TOGETHER by the same author, and
  *     some of those choices were revised during kernel work (round 1: centred decomposition; round 2: balanced
- *     key-switch digits).  Word-for-word agreement between the two is therefore agreement with that specification, not
+ *     key-switch digits, mean-compensated modulus switch).  Word-for-word agreement between the two is therefore agreement with that specification, not
  *     with any external implementation.  What ties the path to the reference is the DECRYPTED level only: every change
  *     of convention is committed together with a green run of tests/test_oracle_tfhe.py (decrypt == the reference's
  *     cleartext goldens, all table modes) -- a change that breaks decryption cannot hide behind GPU == oracle.
