@@ -45,6 +45,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=None, help="key-generation seed (default: fresh from os.urandom)")
     ap.add_argument("--reduced-noise", action="store_true",
                     help="benchmark parameter set with reduced noise (NOT secure) instead of the 128-bit selector")
+    ap.add_argument("--no-shared-rotations", action="store_true",
+                    help="give every table a blind rotation of its own, even where several read one linear combination")
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
 
@@ -56,7 +58,8 @@ def main(argv=None):
     np.random.seed(42)
     values = {name: np.random.randint(0, 2, (args.samples)) for name in order}
 
-    cfg = ExecConfig(fbs_size=args.fbs_size, seed=args.seed, device=args.device, reduced_noise=args.reduced_noise)
+    cfg = ExecConfig(fbs_size=args.fbs_size, seed=args.seed, device=args.device, reduced_noise=args.reduced_noise,
+                     fuse_tables=False if args.no_shared_rotations else None)
     stats = env.stats()
     t0 = time.perf_counter()
     out = env.eval(values, config=cfg)          # first call: key generation + upload + program load + run
@@ -70,10 +73,14 @@ def main(argv=None):
                   outputs={str(k): (int(v) if np.ndim(v) == 0 else int(np.asarray(v).sum())) for k, v in out.items()})
     from dataclasses import asdict
     from .params import margin_sigmas, security_bits
-    for ctx in cfg._contexts.values():
+    for prog, _ in cfg._programs.values():
+        ctx = prog.ctx
+        norm2 = env.fusion_stats(ctx.params.p_msg)["norm2_linprod"] if prog.fused else stats["norm2_linprod"]
         result["params"] = asdict(ctx.params)
         result["security_bits_estimate"] = round(security_bits(ctx.params), 1)
-        result["margin_sigmas"] = round(margin_sigmas(ctx.params, stats["norm2_linprod"]), 2)
+        result["margin_sigmas"] = round(margin_sigmas(ctx.params, norm2), 2)
+        result["blind_rotations"] = prog.n_rotations          # < nb_bootstrap where tables share a rotation
+        result["shared_rotations"] = prog.fused
     if bits is not None:
         clear = bits.eval(values)
         result["matches_cleartext_netlist"] = all(
