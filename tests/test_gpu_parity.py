@@ -434,3 +434,18 @@ def test_matrix_core_key_switch_equals_the_integer_kernels(nat, n, log_n, l, bet
     ctx.bootstrap_batch(tv, cts, ids)
     assert "k_ks_gemm" in ctx.profile_read()["keyswitch"]["kernel"]
     assert np.array_equal(whole, parts)
+
+
+def test_matrix_core_key_switch_over_several_passes_and_changing_batch_sizes(nat, toy_params):
+    """The GEMM key switch works in passes of 8192 ciphertexts, and its scratch (the limb sums, the rounding-error sums)
+    is handed from launch to launch all zero: a long batch (two passes, the second ragged), then short ones, each against
+    the integer kernels on slices of 64."""
+    prm = toy_params.replace(log_n_poly=8, n=20)
+    ctx = nat.Context(prm, seed=4)
+    tv = ctx.tvset([[0, 1, 1, 0, 1, 0, 0]])
+    rng = np.random.default_rng(0)
+    for count in (8192 + 77, 65, 700, 129, 8192):
+        cts = ctx.encrypt(rng.integers(0, 7, count), nonce0=count)
+        whole = ctx.bootstrap_batch(tv, cts)
+        parts = np.concatenate([ctx.bootstrap_batch(tv, cts[i:i + 64]) for i in range(0, count, 64)])
+        assert np.array_equal(whole, parts), count
