@@ -273,3 +273,20 @@ def test_default_config_fuses_where_it_pays_and_decrypts_to_the_reference(name):
         assert np.array_equal(np.asarray(got2[k]).reshape(-1), np.asarray(v).reshape(-1)), k
     (prog2, _), = off._programs.values()
     assert not prog2.fused and prog2.n_rotations == stats["nb_bootstrap"]
+
+
+def test_load_options_and_queries_fail_with_codes(nat, toy_params):
+    import ctypes as C
+    ctx = nat.Context(toy_params, seed=6)
+    tv = ctx.tvset([[0, 1, 1, 0]])
+    keep = (np.array([1], np.uint8), np.array([0], np.uint32), np.array([0], np.uint32), np.array([0], np.int64),
+            np.zeros(1, np.int64), np.zeros(1, np.uint32), np.array([1], np.int64))        # one Bootstrap of the input
+    desc = nat._ProgramDesc(1, 1, 0, 1, *[a.ctypes.data for a in keep])
+    h = C.c_void_p()
+    assert nat.lib.fbs_program_load_ex(ctx._h, C.byref(desc), tv._h, 2, C.byref(h)) == -1 and not h.value     # unknown flag
+    assert "unknown load flag" in nat.lib.fbs_last_error(ctx._h).decode()
+    d, g = C.c_uint64(), C.c_uint64()
+    assert nat.lib.fbs_table_fusion_norms(tv._h, 1, C.byref(d), C.byref(g)) == -1                               # no such table
+    assert nat.lib.fbs_table_fusion_norms(tv._h, 0, C.byref(d), None) == 0 and d.value == 2
+    with pytest.raises(nat.FbsError):
+        tv.fusion_norms(7)
