@@ -74,3 +74,54 @@ def test_random_program(seed):
     expect = lut_oracle.eval_fbs_text(buf.getvalue(), ins)
     got = env.eval(ins, config=ExecConfig(fbs_size=P, seed=1, reduced_noise=True))
     assert_outputs_equal(got, {k: (int(v) if np.ndim(v) == 0 else np.asarray(v, np.int64)) for k, v in expect.items()})
+
+
+def random_shared_program(seed):
+    """As above, but most linear combinations get two to four tables (distinct ones: the builder merges identical tables on
+    one source, fbs_exec_env.py:93-100) -- the shape that shares blind rotations."""
+    from tfhe_fbs_map_amd import LutExecEnv, table_is_valid
+    rng = np.random.default_rng(5000 + seed)
+    env = LutExecEnv()
+    nodes = [env.input("i%d" % k) for k in range(int(rng.integers(3, 6)))]
+    shared = 0
+    for _ in range(int(rng.integers(8, 20))):
+        fan = int(rng.integers(1, 4))
+        picks = [nodes[int(rng.integers(0, len(nodes)))] for _ in range(fan)]
+        coefs = [int(rng.integers(-2, 4)) or 1 for _ in range(fan)]
+        lo = sum(min(0, c * env.max_val[v.name]) for c, v in zip(coefs, picks))
+        lin = env.linear(coefs, picks, const_coef=int(rng.integers(0, 2)) - lo)
+        width = env.max_val[lin.name] + 1
+        if width > 2 * P or width < 2:
+            continue
+        made = 0
+        for _ in range(int(rng.integers(1, 5))):
+            table = random_table(rng, width)
+            if min(table) != 0 or max(table) == 0 or not table_is_valid(table, P):
+                continue
+            nodes.append(env.bootstrap(lin, table))
+            made += 1
+        shared += made >= 2
+    for k, node in enumerate(nodes[-6:]):
+        env.output("o%d" % k, node)
+    return env, shared
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_program_with_shared_sources(seed):
+    """Several random tables (multi-valued, all negacyclic modes) per linear combination, evaluated with shared blind
+    rotations: every output equals the cleartext oracle's, and fewer rotations ran than there are tables."""
+    from tfhe_fbs_map_amd import ExecConfig
+    env, shared = random_shared_program(seed)
+    if shared == 0:
+        pytest.skip("generator produced no shared source")
+    rng = np.random.default_rng(2000 + seed)
+    names = [i.name for i in env.instructions if isinstance(i, type(env).Input)]
+    ins = {n: rng.integers(0, 2, 24) for n in names}
+    buf = io.StringIO()
+    env.print(os=buf, show_outputs=True)
+    expect = lut_oracle.eval_fbs_text(buf.getvalue(), ins)
+    cfg = ExecConfig(fbs_size=P, seed=1, reduced_noise=True, fuse_tables=True)
+    got = env.eval(ins, config=cfg)
+    assert_outputs_equal(got, {k: (int(v) if np.ndim(v) == 0 else np.asarray(v, np.int64)) for k, v in expect.items()})
+    (prog, _), = cfg._programs.values()
+    assert prog.fused and prog.n_rotations < prog.n_bootstrap
