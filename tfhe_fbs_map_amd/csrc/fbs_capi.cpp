@@ -218,7 +218,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_ks_a, (void *)ctx->d_ks_b, (void *)ctx->d_ks_c, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_ks_a, (void *)ctx->d_ks_b, (void *)ctx->d_ks_c, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc, (void *)ctx->d_stage_in, (void *)ctx->d_stage_out, (void *)ctx->d_stage_ids,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
@@ -388,39 +388,31 @@ int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_i
     if (table_ids)
         for (size_t i = 0; i < count; i++)
             if (table_ids[i] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
+    // device staging owned by the context (grown on demand, reused from call to call: no allocation on the steady path)
     const size_t words = count * (ctx->D + 1);
-    uint64_t *d_in = nullptr, *d_out = nullptr;
-    uint32_t *d_tab = nullptr;
-    auto cleanup = [&] {
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
-        if (d_tab) (void)hipFree(d_tab);
-    };
-#define TRY(call)                                                                                           \
-    do {                                                                                                    \
-        hipError_t e__ = (call);                                                                            \
-        if (e__ != hipSuccess) {                                                                            \
-            cleanup();                                                                                      \
-            return set_error(ctx, FBS_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__));        \
-        }                                                                                                   \
-    } while (0)
-    TRY(hipMalloc(&d_in, words * 8));
-    TRY(hipMalloc(&d_out, words * 8));
-    TRY(hipMemcpyAsync(d_in, cts_in, words * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (table_ids) {
-        TRY(hipMalloc(&d_tab, count * 4));
-        TRY(hipMemcpyAsync(d_tab, table_ids, count * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->stage_capacity < count) {
+        if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
+        for (void *p : {(void *)ctx->d_stage_in, (void *)ctx->d_stage_out, (void *)ctx->d_stage_ids})
+            if (p) (void)hipFree(p);
+        ctx->d_stage_in = ctx->d_stage_out = nullptr;
+        ctx->d_stage_ids = nullptr;
+        ctx->stage_capacity = 0;
+        FBS_HIP(ctx, hipMalloc(&ctx->d_stage_in, words * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_stage_out, words * 8));
+        FBS_HIP(ctx, hipMalloc(&ctx->d_stage_ids, count * 4));
+        ctx->stage_capacity = count;
     }
-    rc = fbs_bootstrap_batch_dev(ctx, tv, d_in, d_tab, count, d_out, nullptr);
+    hipStream_t s = ctx->stream;
+    if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;   // the staging buffers are per-context scratch too
+    FBS_HIP(ctx, hipMemcpyAsync(ctx->d_stage_in, cts_in, words * 8, hipMemcpyHostToDevice, s));
+    if (table_ids) FBS_HIP(ctx, hipMemcpyAsync(ctx->d_stage_ids, table_ids, count * 4, hipMemcpyHostToDevice, s));
+    rc = fbs_bootstrap_batch_dev(ctx, tv, ctx->d_stage_in, table_ids ? ctx->d_stage_ids : nullptr, count, ctx->d_stage_out, nullptr);
     if (rc != FBS_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        cleanup();
+        (void)hipStreamSynchronize(s);
         return rc;
     }
-    TRY(hipMemcpyAsync(cts_out, d_out, words * 8, hipMemcpyDeviceToHost, ctx->stream));
-    TRY(hipStreamSynchronize(ctx->stream));
-#undef TRY
-    cleanup();
+    FBS_HIP(ctx, hipMemcpyAsync(cts_out, ctx->d_stage_out, words * 8, hipMemcpyDeviceToHost, s));
+    FBS_HIP(ctx, hipStreamSynchronize(s));
     return FBS_OK;
 }
 

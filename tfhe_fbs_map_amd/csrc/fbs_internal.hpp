@@ -96,6 +96,9 @@ struct fbs_ctx {
     uint64_t *d_ms_body = nullptr;            // [capacity] bodies before their rounding (mean-compensated modulus switch)
     uint64_t *d_acc = nullptr;       // scratch: whole accumulators [capacity][2][N] of rotations several tables share
     size_t acc_capacity = 0;         // in rows
+    uint64_t *d_stage_in = nullptr, *d_stage_out = nullptr;   // device staging of the host-buffer batch call
+    uint32_t *d_stage_ids = nullptr;
+    size_t stage_capacity = 0;       // in ciphertexts
     uint32_t *d_idx = nullptr;       // scratch for index arrays of the host-index wires API
     size_t idx_capacity = 0;
     uint64_t *d_wires = nullptr;     // wire slots of fbs_eval, shared by every program of the context
