@@ -631,6 +631,22 @@ int dev_upload_keys(fbs_ctx *ctx) {
     return set_error(ctx, FBS_E_INVALID, "unsupported N");
 }
 
+// One workgroup per CU -- ALL the waves a CU holds in one barrier domain.  The two waves that share a SIMD then advance
+// in lockstep; as separate workgroups the SIMD's oldest-first arbitration lets one of them run ahead (measured per
+// workgroup with the wall clock, P1024: 6.0 ms for the favoured ones, 10.7 ms for the others, every XCD alike), and once
+// the favoured half has left, the rest runs with one wave per SIMD and nothing to cover its stalls: 10.7 ms per 1024-batch
+// against 10.0 ms in lockstep.  It pays when the launch fills whole rounds (a round = what the chip holds at once: 600
+// bootstraps take 9.1 ms as small workgroups, 10.05 ms as whole-CU ones); beyond a few rounds the hardware refills freed
+// slots anyway.  Measured and NOT adopted for the other shapes: two-level sets at N = 1024 (no difference), N = 2048 with
+// two bootstraps per workgroup (pairs 10.13 against 9.94 ms, l = 2 23.1 against 21.7 ms: the transforms' own barriers then
+// span eight waves).
+static bool whole_cu_workgroups(size_t count, size_t per_round) {
+    static const bool off = getenv("FBS_BR_SMALL_WORKGROUPS") != nullptr;   // (A/B switch)
+    if (off || count > 4 * per_round) return false;
+    const size_t r = count % per_round;
+    return r == 0 || 8 * r >= 7 * per_round;
+}
+
 int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream) {
     const fbs_params &p = ctx->p;
     BrArgs a{};
@@ -691,6 +707,11 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
+    if (p.log_n_poly == 10 && dig == 3 && whole_cu_workgroups(count, 4 * (size_t)ctx->cu_count)) {
+        // the benchmark shape: four bootstraps = the eight waves of a CU in one workgroup
+        ctx->prof.kernel[1] = "k_blind_rotate<10,6,3,4>";
+        hipLaunchKernelGGL((k_blind_rotate<10, 6, 3, 4>), dim3((unsigned)((count + 3) / 4)), dim3((2 << 6) * 4), 0, stream, a);
+    } else
     switch (p.log_n_poly) {
 #define LAUNCH_LL(L, LL_, DIG, FPW)                                                                                    \
     do {                                                                                                               \
