@@ -34,6 +34,33 @@ struct BrArgs {
     const double *psi_pow;   // [N] psi^x, centred (two key bits per step only)
 };
 
+// Issue priority of the two waves that share a SIMD.  They sit in wave slots 0 and 1 of it (HW_ID bits 3:0); left alone,
+// the SIMD issues the older one first whenever both are ready.  PRIO = 1: the priority is raised on even steps in one slot
+// and on odd steps in the other; PRIO = 7: it also changes hands in the middle of a step (before the inverse transform), so
+// that within each half of a step one wave leads and the other fills its stalls, and neither leads for long.
+// Measured (tools/selector_bench.py, one box, FBS/s without / PRIO 1 / PRIO 7): N = 1024 one polynomial per wave: p = 2
+// 148.3 / 153.0 / 155.0 k, p = 4 125.0 / 126.8 / 129.7 k, and the benchmark shape in whole-CU workgroups 100.0 / 106.8 /
+// 110.0 k; N = 2048 (two waves per polynomial): (15, 70) 100.1 / 101.0 / 36 k, (31, 325) 46.3 / 46.8 / 24 k -- a change of
+// hands between the barriers of a multi-wave transform stalls the polynomial's other wave.
+#ifndef FBS_PRIO_ONE_WAVE
+#define FBS_PRIO_ONE_WAVE 7    // polynomials that live in one wave (N <= 1024)
+#endif
+#ifndef FBS_PRIO_MULTI_WAVE
+#define FBS_PRIO_MULTI_WAVE 1  // polynomials spread over several waves
+#endif
+__device__ __forceinline__ uint32_t wave_slot_parity() {
+    uint32_t hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    return hw_id & 1u;
+}
+template <int PRIO>
+__device__ __forceinline__ void lead_if(uint32_t turn, uint32_t slot) {
+    if constexpr (PRIO != 0) {
+        if ((turn ^ slot) & 1u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int LOGN, int LL>
 __global__ __launch_bounds__(1 << LL) void k_bsk_transform(const uint64_t *__restrict__ src, double *__restrict__ dst,
@@ -168,7 +195,10 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     }
 
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
+    constexpr int PRIO = LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
+    const uint32_t slot = PRIO ? wave_slot_parity() : 0u;
     for (uint32_t i = 0; i < a.n; i++) {
+        lead_if<PRIO>(PRIO == 7 ? 2u * i : i, slot);
         const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
         r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
         if (r == 0) {           // X^0 * ACC - ACC = 0: nothing to add (uniform over the two waves of a bootstrap)
@@ -272,6 +302,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             for (int m = 0; m < E; m++) own[m] += mine[slot + W::handoff_word(t, m)];
         }
 
+        if constexpr (PRIO == 7) lead_if<PRIO>(2u * i + 1u, slot);
         // ---- back to coefficients (the 1/N is folded into the key) and accumulate ---------------
         W::template inverse<BOUNDED>(own, xc, t, twi, inv_uni);
 #pragma unroll
@@ -389,7 +420,10 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 
     const uint32_t n_pairs = a.n / 2;
     uint32_t e0_next = ms[0], e1_next = ms[1];
+    constexpr int PRIO = LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
+    const uint32_t slot = PRIO ? wave_slot_parity() : 0u;
     for (uint32_t i = 0; i < n_pairs; i++) {
+        lead_if<PRIO>(PRIO == 7 ? 2u * i : i, slot);
         uint32_t e[3];
         e[0] = __builtin_amdgcn_readfirstlane(e0_next);
         e[1] = __builtin_amdgcn_readfirstlane(e1_next);
@@ -507,6 +541,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
             for (int m = 0; m < E; m++) own[m] += mine[W::handoff_word(t, m)];
         }
+        if constexpr (PRIO == 7) lead_if<PRIO>(2u * i + 1u, slot);
         W::template inverse<true>(own, xc, t, twi, inv_uni);   // 2l products below 0.8 q each: l <= 5 (the launcher checks)
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
@@ -637,7 +672,8 @@ int dev_upload_keys(fbs_ctx *ctx) {
 // the favoured half has left, the rest runs with one wave per SIMD and nothing to cover its stalls: 10.7 ms per 1024-batch
 // against 10.0 ms in lockstep.  It pays when the launch fills whole rounds (a round = what the chip holds at once: 600
 // bootstraps take 9.1 ms as small workgroups, 10.05 ms as whole-CU ones); beyond a few rounds the hardware refills freed
-// slots anyway.  Measured and NOT adopted for the other shapes: two-level sets at N = 1024 (no difference), N = 2048 with
+// slots anyway.  Measured and NOT adopted for the other shapes: two-level sets at N = 1024 (slower with the priority hand-over below:
+// 152.5 against 155.5 k FBS/s at p = 2, 124 against 131 k at p = 4), N = 2048 with
 // two bootstraps per workgroup (pairs 10.13 against 9.94 ms, l = 2 23.1 against 21.7 ms: the transforms' own barriers then
 // span eight waves).
 static bool whole_cu_workgroups(size_t count, size_t per_round) {
