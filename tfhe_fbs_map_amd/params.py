@@ -119,23 +119,25 @@ def bootstrap_cost(prm: Params) -> float:
     the default P1024 shape = 1.  Per CMUX step and coefficient, from the instruction counts of k_blind_rotate (DESIGN.md
     section 5): (k+1)(l+1) transforms of log N / 2 butterflies of 8 instructions, (k+1)^2 l exact products of 7 (accumulate
     included), 2 l for the digits and 12 for rotation, rounding and re-centring; times n steps, times what the multi-wave
-    transforms of N >= 2048 cost on top (measured: 1.11 at N = 2048, 1.15 at N = 4096).  Against measurements (profiles/r02/
-    selector_bench.jsonl): N = 1024 l = 2 0.77 modelled / 0.79 measured; N = 2048 l = 1 1.33 / 1.33; N = 2048 l = 2 2.16 /
-    2.13; N = 4096 l = 2 5.2 / 5.2.  The kN t (n+1) multiply-adds of the key switch are weighted by their measured share
-    (1.5 % of the P1024 step since it runs as an int8 GEMM on the matrix cores; 5 % before).  The reference ranks parameter
+    transforms of N >= 2048 cost on top -- and what they do NOT gain from the whole-CU workgroups and the priority
+    hand-over that sped the benchmark shape up at the end of round 2 (measured: 1.19 at N = 2048, 1.22 at N = 4096).
+    Against measurements (profiles/r02/selector_bench.jsonl, blind rotation per 1024-batch over P1024's 9.33 ms): N = 1024
+    l = 2 0.67-0.76 modelled / 0.69-0.82 measured; N = 2048 l = 1 1.41 / 1.41; N = 2048 l = 2 2.32 / 2.30; N = 4096 l = 2
+    5.5 / 5.5.  The kN t (n+1) multiply-adds of the key switch are weighted by their measured share
+    (1.2 % of the P1024 step since it runs as an int8 GEMM on the matrix cores; 5 % before).  The reference ranks parameter
     sets by the optimizer's `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
 
     def blind(n_, l_, N_, log_n):
         per_coefficient = (k + 1) * ((l_ + 1) * 4.0 * log_n + 7.0 * (k + 1) * l_ + 2.0 * l_ + 12.0)
-        return n_ * N_ * per_coefficient * (1.15 if log_n >= 12 else 1.11 if log_n == 11 else 1.0)
+        return n_ * N_ * per_coefficient * (1.22 if log_n >= 12 else 1.19 if log_n == 11 else 1.0)
 
-    # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.72 with one
-    # gadget level (10.0 against 14.0 ms per 1024 bootstraps at N = 2048, n = 714 / 710).  With l levels the bundle costs
+    # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.74 with one
+    # gadget level (9.8 against 13.2 ms per 1024 bootstraps at N = 2048, n = 714 / 710).  With l levels the bundle costs
     # 6 l exact products per coefficient and pair of key bits where it saves l + 1 transforms: it does not pay beyond
     # l = 1 (P1024, l = 3: 13.5 against 10.8 ms)
-    pairs = 1.0 if prm.bsk_group != 2 else (0.72 if l == 1 else 1.25)
-    return 0.985 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.015 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
+    pairs = 1.0 if prm.bsk_group != 2 else (0.74 if l == 1 else 1.25)
+    return 0.988 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
 # ---- selector ------------------------------------------------------------------------------------------------------
