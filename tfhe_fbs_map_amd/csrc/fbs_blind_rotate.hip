@@ -676,11 +676,14 @@ int dev_upload_keys(fbs_ctx *ctx) {
 // 152.5 against 155.5 k FBS/s at p = 2, 124 against 131 k at p = 4), N = 2048 with
 // two bootstraps per workgroup (pairs 10.13 against 9.94 ms, l = 2 23.1 against 21.7 ms: the transforms' own barriers then
 // span eight waves).
-static bool whole_cu_workgroups(size_t count, size_t per_round) {
+// How many bootstraps of a launch of `count` go to whole-CU workgroups: all of them when the last round is (nearly) full,
+// else the whole rounds only -- the rest follows as a launch of its own in the shape that suits its size (a partly
+// filled round is faster as small workgroups: 768 bootstraps 8.2 ms against 9.3).
+static size_t whole_cu_share(size_t count, size_t per_round) {
     static const bool off = getenv("FBS_BR_SMALL_WORKGROUPS") != nullptr;   // (A/B switch)
-    if (off || count > 4 * per_round) return false;
+    if (off) return 0;
     const size_t r = count % per_round;
-    return r == 0 || 8 * r >= 7 * per_round;
+    return (r == 0 || 8 * r >= 7 * per_round) ? count : count - r;
 }
 
 int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream) {
@@ -743,10 +746,21 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
-    if (p.log_n_poly == 10 && dig == 3 && whole_cu_workgroups(count, 4 * (size_t)ctx->cu_count)) {
+    const size_t whole = (p.log_n_poly == 10 && dig == 3) ? whole_cu_share(count, 4 * (size_t)ctx->cu_count) : 0;
+    if (whole) {
         // the benchmark shape: four bootstraps = the eight waves of a CU in one workgroup
+        a.count = whole;
+        a.gv.count = whole;
         ctx->prof.kernel[1] = "k_blind_rotate<10,6,3,4>";
-        hipLaunchKernelGGL((k_blind_rotate<10, 6, 3, 4>), dim3((unsigned)((count + 3) / 4)), dim3((2 << 6) * 4), 0, stream, a);
+        hipLaunchKernelGGL((k_blind_rotate<10, 6, 3, 4>), dim3((unsigned)((whole + 3) / 4)), dim3((2 << 6) * 4), 0, stream, a);
+        prof_end(ctx, 1, stream, e0, e1);
+        FBS_HIP(ctx, hipGetLastError());
+        if (whole == count) return FBS_OK;
+        GateView rest = gv;                       // what did not fill a round: its own launch, in the shape its size asks for
+        rest.f_begin += whole;
+        rest.count = count - whole;
+        if (rest.out_rows) rest.out_rows += whole * (size_t)(ctx->D + 1);
+        return dev_blind_rotate(ctx, tv, rest, d_ms, stream);
     } else
     switch (p.log_n_poly) {
 #define LAUNCH_LL(L, LL_, DIG, FPW)                                                                                    \
