@@ -116,7 +116,11 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 // every workgroup at the same SIMD often enough that two-wave workgroups pile up on two SIMDs while the other two
 // idle whenever a CU holds fewer than four of them (measured: 512 bootstraps took 9.7 ms, 256 took 5.7 ms); four-wave
 // workgroups (two bootstraps) always cover all four SIMDs.
-template <int LOGN, int LL, int DIG, int FPW>
+// TURNS: the two waves of a SIMD hand the issue priority back and forth (lead_if).  It pays while a launch is a round or two
+// long; small workgroups of a long launch are refilled as they finish and do better left alone -- and the mere presence of
+// s_setprio costs the compiler's schedule 7 % there (N = 1024, l = 2, 8192 bootstraps: 118 k FBS/s with, 134 k without;
+// 1024 bootstraps: 129 against 125), so the launcher picks an instantiation, not a flag.
+template <int LOGN, int LL, int DIG, int FPW, bool TURNS = true>
 __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = typename NttFor<LOGN, LL>::type;
     constexpr int FIRST = (DIG == 3 || DIG == 7) ? 2 : (DIG == 2 || DIG == 6) ? 1 : 0;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     }
 
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
-    constexpr int PRIO = LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
+    constexpr int PRIO = !TURNS ? 0 : LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
     const uint32_t slot = PRIO ? wave_slot_parity() : 0u;
     for (uint32_t i = 0; i < a.n; i++) {
         lead_if<PRIO>(PRIO == 7 ? 2u * i : i, slot);
@@ -761,6 +765,15 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         rest.count = count - whole;
         if (rest.out_rows) rest.out_rows += whole * (size_t)(ctx->D + 1);
         return dev_blind_rotate(ctx, tv, rest, d_ms, stream);
+    } else if (p.log_n_poly == 10 && (dig == 6 || dig == 7) && count > 8 * (size_t)ctx->cu_count) {
+        // the two-level 128-bit sets at N = 1024 in launches of more than two rounds: no taking turns (see TURNS)
+        if (dig == 6) {
+            ctx->prof.kernel[1] = "k_blind_rotate<10,6,6,1,false>";
+            hipLaunchKernelGGL((k_blind_rotate<10, 6, 6, 1, false>), grid, dim3(2 << 6), 0, stream, a);
+        } else {
+            ctx->prof.kernel[1] = "k_blind_rotate<10,6,7,1,false>";
+            hipLaunchKernelGGL((k_blind_rotate<10, 6, 7, 1, false>), grid, dim3(2 << 6), 0, stream, a);
+        }
     } else
     switch (p.log_n_poly) {
 #define LAUNCH_LL(L, LL_, DIG, FPW)                                                                                    \

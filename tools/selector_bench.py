@@ -18,7 +18,7 @@ for p, norm2 in cases:
     ctx = Context(prm, seed=1)
     rng = np.random.default_rng(1)
     tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(16)]
-    B = 1024
+    B = int(os.environ.get("BATCH", 1024))
     msgs = rng.integers(0, p, B)
     ids = (np.arange(B) % 16).astype(np.uint32)
     tv = ctx.tvset(tables)
