@@ -678,8 +678,9 @@ int dev_upload_keys(fbs_ctx *ctx) {
 // bootstraps take 9.1 ms as small workgroups, 10.05 ms as whole-CU ones); beyond a few rounds the hardware refills freed
 // slots anyway.  Measured and NOT adopted for the other shapes: two-level sets at N = 1024 (slower with the priority hand-over below:
 // 152.5 against 155.5 k FBS/s at p = 2, 124 against 131 k at p = 4), N = 2048 with
-// two bootstraps per workgroup (pairs 10.13 against 9.94 ms, l = 2 23.1 against 21.7 ms: the transforms' own barriers then
-// span eight waves).
+// two bootstraps per workgroup (pairs 10.13 against 9.94 ms, l = 2 23.1 against 21.7 ms; with the priority hand-over as
+// well: 10.34 against 9.87 ms at 1024 bootstraps, 82.4 against 73.7 ms at 8192 -- the transforms' own barriers then span
+// eight waves).
 // How many bootstraps of a launch of `count` go to whole-CU workgroups: all of them when the last round is (nearly) full,
 // else the whole rounds only -- the rest follows as a launch of its own in the shape that suits its size (a partly
 // filled round is faster as small workgroups: 768 bootstraps 8.2 ms against 9.3).
