@@ -182,3 +182,40 @@ def test_samples_are_chunked_when_the_wire_slots_do_not_fit(nat, toy_params, mon
     assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ref)
     for k, name in enumerate(low["out_names"]):
         assert np.array_equal(ctx2.decrypt(ref[k]), expect[name])
+
+
+def test_long_level_into_rows_runs_as_whole_rounds_plus_a_remainder(nat):
+    """A level of the benchmark shape longer than a round is launched as whole rounds in whole-CU workgroups and the rest as a
+    launch of its own (csrc/fbs_blind_rotate.hip, whole_cu_share) -- also when the results go to a contiguous row buffer
+    (the send buffer of the gate-sharded mode) and when the range starts in the middle of the level."""
+    import torch
+    from tfhe_fbs_map_amd import P1024, parse_fbs
+    prm = P1024.replace(n=16, p_msg=7)                     # l = 3, beta = 7 at N = 1024: the benchmark kernels, short rotation
+    text = "m1 = 1 * a + 2 * b\nm2 = Bootstrap(m1, [0, 1, 1, 0])\nm3 = Bootstrap(m2, [1, 0])\nOutput x = m2\nOutput y = m3\n"
+    env = parse_fbs(text, inputs=["a", "b"])
+    low = env.lower()
+    ctx = nat.Context(prm, seed=2)
+    prog = nat.Program(ctx, ctx.tvset(low["tables"]), 2, low["kind"], low["arg0"], low["arg1"], low["const_coef"],
+                       low["term_coef"], low["term_src"], low["out_wire"])
+    T = 1700                                               # one round (1024) + 676
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2, (2, T))
+    cts = ctx.encrypt(bits, nonce0=1)
+    ref = prog.eval(cts, T)
+    assert np.array_equal(ctx.decrypt(ref[0]), np.array([0, 1, 1, 0])[bits[0] + 2 * bits[1]])
+    ctw = prm.ct_words
+    wires = torch.zeros((prog.n_slots, T, ctw), dtype=torch.int64, device="cuda")
+    wires[torch.from_numpy(prog.in_slot.astype(np.int64)).cuda()] = torch.from_numpy(cts.view(np.int64)).cuda()
+    for L in range(prog.depth + 1):
+        prog.level_lincomb_dev(L, wires.data_ptr(), T, 0, T)
+        if L == prog.depth:
+            break
+        total = prog.level_width[L] * T
+        for f0, f1 in ((0, 1300), (1300, total)):          # 1300 = a round and 276; the second range starts mid-level
+            rows = torch.full((f1 - f0, ctw), -1, dtype=torch.int64, device="cuda")
+            prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, f0, f1, d_rows=rows.data_ptr())
+            prog.level_scatter_dev(L, wires.data_ptr(), T, 0, T, rows.data_ptr(), f0, f1)
+    ctx.sync()
+    got = wires.cpu().numpy().view(np.uint64)
+    for k, slot in enumerate(prog.out_slot.tolist()):
+        assert np.array_equal(got[slot], ref[k]), low["out_names"][k]
