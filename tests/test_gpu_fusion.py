@@ -290,3 +290,26 @@ def test_load_options_and_queries_fail_with_codes(nat, toy_params):
     assert nat.lib.fbs_table_fusion_norms(tv._h, 0, C.byref(d), None) == 0 and d.value == 2
     with pytest.raises(nat.FbsError):
         tv.fusion_norms(7)
+
+
+def test_shared_rotations_in_a_level_longer_than_a_round(nat):
+    """The benchmark shape (l = 3, beta = 7, N = 1024) launches whole rounds as whole-CU workgroups and the rest separately
+    (whole_cu_share): the accumulators of shared rotations must land in their scratch rows on both sides of the cut."""
+    from tfhe_fbs_map_amd import P1024
+    prm = P1024.replace(n=16, p_msg=7)
+    T = 700                                                # level 1: 2 rotations x 700 = a round and 376
+    ctx, low, tv, prog = load(nat, prm, MULTI, ["a", "b", "c"])
+    assert prog.n_rotations == 3 and prog.n_bootstrap == 7
+    rng = np.random.default_rng(8)
+    bits = rng.integers(0, 2, (3, T))
+    cts = ctx.encrypt(bits, nonce0=2)
+    got = prog.eval(cts, T)
+    clear = lut_oracle.eval_fbs_text(MULTI, {n: bits[i] for i, n in enumerate(low["input_names"])})
+    for k, name in enumerate(low["out_names"]):
+        assert np.array_equal(ctx.decrypt(got[k]) % 14, np.asarray(clear[name]) % 14), name
+    ops, outs = lut_oracle.read_fbs(MULTI)                 # and word for word against the oracle on the samples around the cut
+    o = orc.Oracle(prm, seed=6)
+    pick = np.array([0, 1, 322, 323, 324, 325, 699])       # 1024 = 700 + 324: the cut falls at sample 324 of the second rotation
+    wires = oracle_eval_program(o, ops, outs, {n: cts[i][pick] for i, n in enumerate(low["input_names"])}, fuse=True)
+    for k, (out_name, src) in enumerate(outs):
+        assert np.array_equal(got[k][pick], wires[src]), out_name
