@@ -10,7 +10,7 @@ from tfhe_fbs_map_amd.params import margin_sigmas, security_bits
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 skip_big = ("trivium_stream", "kreyvium_stream")
-cfg = ExecConfig(seed=2026)
+cfg = ExecConfig(seed=2026, reduced_noise=bool(os.environ.get("REDUCED_NOISE")))   # REDUCED_NOISE=1: the benchmark sets (whole-CU kernels)
 rows, bad = [], []
 t_all = time.time()
 for name in fixture_names():
@@ -45,5 +45,5 @@ summary = dict(samples=T, fixtures=len(rows), all_ok=not bad, failures=bad, boot
                poly_sizes=sorted({r["N"] for r in rows if r["N"]}),
                seconds=round(time.time() - t_all, 1), rows=rows)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(summary, open("gpurun_out/secure_all_fixtures.json", "w"), indent=1)
+json.dump(summary, open("gpurun_out/%s_all_fixtures.json" % ("reduced_noise" if os.environ.get("REDUCED_NOISE") else "secure"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "rows"}))
