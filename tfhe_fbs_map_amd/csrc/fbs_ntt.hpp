@@ -121,8 +121,11 @@ struct PolyNtt {
     };
 
     // distinct twiddles of stage s for this lane: one per block of registers the stage pairs up, j = m >> (bit + 1)
+    // R: node of the twiddle tree the transform hangs from (1 = a whole polynomial; W + w when it is part w of a polynomial W
+    // times the size, WavesNtt in fbs_ntt_split.hpp).  Only the wave-uniform reads index the big tree with it; `tw.lane`
+    // always points at a table of this transform's own tree.
     template <int G>
-    __device__ static __forceinline__ void load_stage(int s, uint32_t t, const Twiddles &tw, double (&w)[E / 2]) {
+    __device__ static __forceinline__ void load_stage(int s, uint32_t t, const Twiddles &tw, double (&w)[E / 2], uint32_t R = 1) {
         constexpr int lo = lo_of(G);
         const int bit = LOGN - 1 - s - lo;     // register-index bit paired by this stage
         const int sh = lo + LOGE - LOGN + s;   // how far the lane's high part reaches into the block id
@@ -131,7 +134,7 @@ struct PolyNtt {
         for (int j = 0; j < E / 2; j++) {
             if (j >= (E >> (bit + 1))) continue;
             // lo >= LL: the lane's high part is empty, the index depends on the register only
-            w[j] = lo >= LL ? tw.uniform[(1u << s) + (uint32_t)j] : tw.lane[(1u << s) + ((hi_part << sh) | (uint32_t)j)];
+            w[j] = lo >= LL ? tw.uniform[(R << s) + (uint32_t)j] : tw.lane[(1u << s) + ((hi_part << sh) | (uint32_t)j)];
         }
     }
 
@@ -139,17 +142,17 @@ struct PolyNtt {
     // the stage before it, so their (LDS or scalar-cache) latency hides behind arithmetic.
     // FIRST describes the inputs of the transform and with them the very first stage (see `first_butterfly`)
     template <int G, int FIRST>
-    __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
+    __device__ static __forceinline__ void fwd_group(double (&x)[E], uint32_t t, const Twiddles &tw, uint32_t R = 1) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
         double w[LOGE + 1][E / 2];
-        load_stage<G>(s_begin, t, tw, w[0]);
+        load_stage<G>(s_begin, t, tw, w[0], R);
 #pragma unroll
         for (int s = s_begin; s < s_end; s++) {
             const int bit = LOGN - 1 - s - lo;   // register-index bit paired by this stage
             const int hm = 1 << bit;
-            if (s + 1 < s_end) load_stage<G>(s + 1, t, tw, w[s + 1 - s_begin]);
+            if (s + 1 < s_end) load_stage<G>(s + 1, t, tw, w[s + 1 - s_begin], R);
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
@@ -167,19 +170,19 @@ struct PolyNtt {
     }
     // Gentleman-Sande stages of group G, last stage first
     template <int G>
-    __device__ static __forceinline__ void inv_group(double (&x)[E], uint32_t t, const Twiddles &tw) {
+    __device__ static __forceinline__ void inv_group(double (&x)[E], uint32_t t, const Twiddles &tw, uint32_t R = 1) {
         constexpr int lo = lo_of(G);
         constexpr int s_begin = G * LOGE;
         constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
         double w[LOGE + 1][E / 2];
-        load_stage<G>(s_end - 1, t, tw, w[s_end - 1 - s_begin]);
+        load_stage<G>(s_end - 1, t, tw, w[s_end - 1 - s_begin], R);
 #pragma unroll
         for (int m = 0; m < E; m++) x[m] = fp_center(x[m]);
 #pragma unroll
         for (int s = s_end - 1; s >= s_begin; s--) {
             const int bit = LOGN - 1 - s - lo;
             const int hm = 1 << bit;
-            if (s > s_begin) load_stage<G>(s - 1, t, tw, w[s - 1 - s_begin]);
+            if (s > s_begin) load_stage<G>(s - 1, t, tw, w[s - 1 - s_begin], R);
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & hm) continue;
@@ -196,28 +199,29 @@ struct PolyNtt {
     // `before_last` runs right before the butterflies of the last group: the place to issue global loads whose
     // results are wanted when the transform ends (one group of butterflies ~ one L2 round trip)
     template <int G, int FIRST, class Hook>
-    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
+    __device__ static __forceinline__ void fwd_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last,
+                                                    uint32_t R = 1) {
         if constexpr (G + 1 == GROUPS) before_last();
-        fwd_group<G, FIRST>(x, t, tw);
+        fwd_group<G, FIRST>(x, t, tw, R);
         if constexpr (G + 1 < GROUPS) {
             double *buf = xc.next();
             if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) sync();   // one buffer: the stores stay behind the reads that filled x
             store_group<G>(buf, t, x);
             sync();
             load_group<G + 1>(buf, t, x);
-            fwd_from<G + 1, FIRST>(x, xc, t, tw, before_last);
+            fwd_from<G + 1, FIRST>(x, xc, t, tw, before_last, R);
         }
     }
     template <int G>
-    __device__ static __forceinline__ void inv_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
-        inv_group<G>(x, t, tw);
+    __device__ static __forceinline__ void inv_from(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, uint32_t R = 1) {
+        inv_group<G>(x, t, tw, R);
         if constexpr (G > 0) {
             double *buf = xc.next();
             if constexpr (LL <= FBS_ONE_BUFFER_MAX_LL) sync();   // one buffer: the stores stay behind the reads that filled x
             store_group<G>(buf, t, x);
             sync();
             load_group<G - 1>(buf, t, x);
-            inv_from<G - 1>(x, xc, t, tw);
+            inv_from<G - 1>(x, xc, t, tw, R);
         }
     }
 
@@ -228,17 +232,19 @@ struct PolyNtt {
     }
     // the same with a promise about the inputs (FIRST, see first_butterfly)
     template <int FIRST, class Hook>
-    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last) {
-        fwd_from<0, FIRST>(x, xc, t, tw, before_last);
+    __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, Hook &&before_last,
+                                                   uint32_t R = 1) {
+        fwd_from<0, FIRST>(x, xc, t, tw, before_last, R);
     }
     // evaluations (last-group layout, |x| < 2^52) -> N * coefficients (group-0 layout, |x| <= 8 q).  BOUNDED (a promise
     // of |x| <= 8 q) is accepted for interface parity with SplitNtt and not used: four-stage groups need the centring.
     // interface parity with SplitNtt (which takes its wave-uniform inverse twiddles from the caller): nothing to carry
     struct InvUniform {};
-    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t, const Twiddles &) { return {}; }
+    __device__ static __forceinline__ InvUniform inverse_uniform(uint32_t, const Twiddles &, uint32_t = 1) { return {}; }
     template <bool BOUNDED = false>
-    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &) {
-        inverse<BOUNDED>(x, xc, t, tw);
+    __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw, const InvUniform &,
+                                                   uint32_t R = 1) {
+        inv_from<GROUPS - 1>(x, xc, t, tw, R);
     }
     template <bool BOUNDED = false>
     __device__ static __forceinline__ void inverse(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {
@@ -268,11 +274,17 @@ struct PolyNtt {
 //   N  = 2048: two waves per polynomial, E = 16, two exchanges per transform through one buffer (two workgroup barriers
 //              each) with the twiddle tables in the LDS a ping-pong pair would have taken: 23.7 ms; with the ping-pong
 //              pair and twiddles from global memory 27.5; four waves with E = 8 and three exchanges 39.7 (l = 4).
-// A second shape for launches that leave most of the chip empty (at most one bootstrap per CU): N = 1024 as two waves
-// per polynomial with 8 coefficients per lane -- twice the waves per bootstrap, 4.95 ms against 5.56 ms per launch.
-// It needs its own transformed copy of the bootstrapping key (the evaluation order differs).  Same as the main
-// shape where there is no such alternative.
-__host__ __device__ constexpr int lanes_log2_for_small_launch(int log_n) { return log_n == 10 ? 7 : (log_n <= 10 ? 6 : log_n - 4); }
+// A second shape for launches that leave most of the chip empty (at most one bootstrap per CU): N = 1024 as FOUR waves
+// per polynomial with 4 coefficients per lane (WavesNtt<10, 2>, fbs_ntt_split.hpp) -- one bootstrap is the eight waves a
+// CU holds of this kernel.  (Round 2: two waves per polynomial with 8 coefficients per lane, the generic PolyNtt<10, 7>
+// with two barriers per exchange: 4.8 ms per bootstrap.)  It needs its own transformed copy of the bootstrapping key (the
+// evaluation order differs).  Same as the main shape where there is no such alternative.
+#ifndef FBS_SMALL_LAUNCH_LL_1024
+#define FBS_SMALL_LAUNCH_LL_1024 8
+#endif
+__host__ __device__ constexpr int lanes_log2_for_small_launch(int log_n) {
+    return log_n == 10 ? FBS_SMALL_LAUNCH_LL_1024 : (log_n <= 10 ? 6 : log_n - 4);
+}
 
 #ifdef FBS_COEFS_PER_LANE_LOG2   // experiments: force 2^k coefficients per lane everywhere it is possible
 __host__ __device__ constexpr int lanes_log2_for(int log_n) {

@@ -13,6 +13,8 @@
 // lane t = coefficient t + 64 m), inverse = GS with centring per group, 1/N folded into the key, evaluation order
 // defined by "whatever forward() leaves in register m of lane t" -- the key transform uses the same code.
 #pragma once
+#include <type_traits>
+
 #include "fbs_ntt.hpp"
 
 namespace fbs {
@@ -273,14 +275,18 @@ struct WavesNtt {
     static constexpr int LL = 6 + LOGW;
     static constexpr int LANES = 64 * W;
     static constexpr int E = N / LANES;
+    static constexpr int LOGE = LOGN - LL;
     static constexpr int EP = E / W;          // registers per part after the cross stages
     static constexpr int M = N / W;
-    using Half = SplitNtt<LOGN - LOGW, 6>;
-    static_assert(E == 16 && Half::E == 16 && (LOGW == 1 || LOGW == 2), "two or four waves, 16 coefficients per lane");
+    // the wave-private transform of a part: the split schedule at 16 coefficients per lane; the plain grouped schedule at 4 or
+    // 8 (N = 1024 or 2048 on four waves: one bootstrap on the eight waves of a CU, the shape of launches that leave most of
+    // the chip empty)
+    using Half = typename std::conditional<E == 16, SplitNtt<(E == 16 ? LOGN - LOGW : 10), 6>, PolyNtt<LOGN - LOGW, 6>>::type;
+    static_assert((E == 16 || E == 8 || E == 4) && Half::E == E && E >= W && (LOGW == 1 || LOGW == 2), "two or four waves, 4, 8 or 16 coefficients per lane");
     // where the per-lane tables start inside the uploaded twiddle buffer: [N whole][N two halves][N four quarters]
     static constexpr int LANE_TABLE_OFFSET = LOGW * N;
     // array position of the evaluation in register m of thread t (see SplitNtt): wave w holds array part w
-    static constexpr bool HAS_EVAL_POSITION = true;
+    static constexpr bool HAS_EVAL_POSITION = E == 16;   // (published for the split schedule only)
     static constexpr int EVAL_GROUP_LOG2 = 2 + LOGW;
     __device__ static __forceinline__ uint32_t eval_position_lane(uint32_t t) { return (t >> 6) * (uint32_t)M + ((t & 63u) << 3); }
     __host__ __device__ static constexpr uint32_t eval_position_reg(int m) { return (uint32_t)(m >> 3) * (M / 2) + (uint32_t)(m & 7); }
@@ -328,7 +334,7 @@ struct WavesNtt {
 #pragma unroll
             for (int m = 0; m < E; m++) {
                 if (m & half) continue;
-                const double wv = tw.uniform[(1u << s) + (uint32_t)(m >> (4 - s))];
+                const double wv = tw.uniform[(1u << s) + (uint32_t)(m >> (LOGE - s))];
                 if (s == 0) {
                     first_butterfly<FIRST>(x[m], x[m + half], wv);
                 } else {
@@ -395,7 +401,7 @@ struct WavesNtt {
                 if (m & half) continue;
                 const double u = x[m], v = x[m + half];
                 x[m] = u + v;
-                x[m + half] = fp_mulmod(u - v, uni.w[(1 << s) - 1 + (m >> (4 - s))]);
+                x[m + half] = fp_mulmod(u - v, uni.w[(1 << s) - 1 + (m >> (LOGE - s))]);
             }
         }
     }
@@ -408,7 +414,7 @@ using PairNtt = WavesNtt<LOGN, 1>;
 #ifndef FBS_PAIR_NTT
 #define FBS_PAIR_NTT 1   // experiments: 0 falls back to the generic two-wave transform for N = 2048
 #endif
-template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : (LL == 8 && LOGN == 12) ? 3 : 0>
+template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : (LL == 8 && (LOGN == 12 || LOGN == 10)) ? 3 : 0>
 struct NttFor {
     using type = PolyNtt<LOGN, LL>;
 };
