@@ -37,3 +37,39 @@ def test_every_exchange_pattern_is_conflict_free():
                 assert len({w % 32 for w in words[32 * g:32 * g + 32]}) == 32, (lo, r, "read")
             for g in range(4):                # ds_write_b64: 16 lanes share 32 banks = 16 eight-byte positions
                 assert len({w % 16 for w in words[16 * g:16 * g + 16]}) == 16, (lo, r, "write")
+
+
+# ---- the one exchange of the 256-point lane-transposition transform (csrc/fbs_ntt_lane.hpp) ----------------------------
+def lane_phys(j):
+    return j ^ ((j >> 4) & 15) ^ (((j >> 6) & 1) << 4)
+
+
+def lane_index_b(ln, m):
+    return ((ln >> 4) << 6) | (m << 4) | (ln & 15)
+
+
+def lane_index_c(ln, m):
+    return ((ln & 15) << 4) | (m << 2) | (ln >> 4)
+
+
+def test_lane_header_uses_these_formulas():
+    text = open(os.path.join(ROOT, "tfhe_fbs_map_amd", "csrc", "fbs_ntt_lane.hpp")).read()
+    m = re.search(r"uint32_t phys\(uint32_t j\) \{ return (.*?); \}", text)
+    assert m and m.group(1).replace("u", "") == "j ^ ((j >> 4) & 15) ^ (((j >> 6) & 1) << 4)"
+    assert "return ((ln >> 4) << 6) | ((uint32_t)m << 4) | (ln & 15u);" in text
+    assert "return ((ln & 15u) << 4) | ((uint32_t)m << 2) | (ln >> 4);" in text
+
+
+def test_lane_exchange_is_a_conflict_free_permutation():
+    assert sorted(lane_phys(j) for j in range(256)) == list(range(256))
+    for a in (1, 8, 64, 77, 200, 255):
+        for b in (2, 16, 128, 99):
+            assert lane_phys(a ^ b) == lane_phys(a) ^ lane_phys(b)
+    for layout in (lane_index_b, lane_index_c):
+        assert sorted(layout(ln, m) for ln in range(64) for m in range(4)) == list(range(256))
+        for m in range(4):
+            words = [lane_phys(layout(ln, m)) for ln in range(64)]
+            for g in range(2):                # read 32 lanes at a time over 32 eight-byte positions
+                assert len({w % 32 for w in words[32 * g:32 * g + 32]}) == 32, (layout.__name__, m, "read")
+            for g in range(4):                # written 16 lanes at a time over 16
+                assert len({w % 16 for w in words[16 * g:16 * g + 16]}) == 16, (layout.__name__, m, "write")

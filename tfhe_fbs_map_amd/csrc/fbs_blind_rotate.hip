@@ -15,51 +15,9 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "fbs_gate.hpp"
-#include "fbs_internal.hpp"
-#include "fbs_ntt.hpp"
-#include "fbs_ntt_split.hpp"
+#include "fbs_blind_rotate.hpp"
 
 namespace fbs {
-
-struct BrArgs {
-    GateView gv;
-    const uint32_t *ms;      // [count][n+1], values in [0, 2N)
-    const double *bsk_hat;   // [n][rows][2][N]  centred, NTT order, times 1/N
-    const double *tw_fwd, *tw_inv;
-    const uint64_t *tvs;     // [tables][N]
-    const uint64_t *post;    // [tables]
-    uint32_t n, l, beta, ct_words, n_tables;
-    size_t count;            // bootstraps in this launch
-    const double *psi_pow;   // [N] psi^x, centred (two key bits per step only)
-};
-
-// Issue priority of the two waves that share a SIMD.  They sit in wave slots 0 and 1 of it (HW_ID bits 3:0); left alone,
-// the SIMD issues the older one first whenever both are ready.  PRIO = 1: the priority is raised on even steps in one slot
-// and on odd steps in the other; PRIO = 7: it also changes hands in the middle of a step (before the inverse transform), so
-// that within each half of a step one wave leads and the other fills its stalls, and neither leads for long.
-// Measured (tools/selector_bench.py, one box, FBS/s without / PRIO 1 / PRIO 7): N = 1024 one polynomial per wave: p = 2
-// 148.3 / 153.0 / 155.0 k, p = 4 125.0 / 126.8 / 129.7 k, and the benchmark shape in whole-CU workgroups 100.0 / 106.8 /
-// 110.0 k; N = 2048 (two waves per polynomial): (15, 70) 100.1 / 101.0 / 36 k, (31, 325) 46.3 / 46.8 / 24 k -- a change of
-// hands between the barriers of a multi-wave transform stalls the polynomial's other wave.
-#ifndef FBS_PRIO_ONE_WAVE
-#define FBS_PRIO_ONE_WAVE 7    // polynomials that live in one wave (N <= 1024)
-#endif
-#ifndef FBS_PRIO_MULTI_WAVE
-#define FBS_PRIO_MULTI_WAVE 1  // polynomials spread over several waves
-#endif
-__device__ __forceinline__ uint32_t wave_slot_parity() {
-    uint32_t hw_id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-    return hw_id & 1u;
-}
-template <int PRIO>
-__device__ __forceinline__ void lead_if(uint32_t turn, uint32_t slot) {
-    if constexpr (PRIO != 0) {
-        if ((turn ^ slot) & 1u) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 template <int LOGN, int LL>
@@ -751,6 +709,15 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool small_launch = ctx->d_bsk_hat_small != nullptr && count <= (size_t)ctx->cu_count;
     hipEvent_t e0, e1;
     prof_begin(ctx, 1, stream, &e0, &e1);
+    {
+        // launches that leave most of the chip empty: one bootstrap on the eight waves of a CU (fbs_blind_rotate_cu.hip)
+        static const int cu_max = getenv("FBS_BR_CU_MAX_PER_CU") ? atoi(getenv("FBS_BR_CU_MAX_PER_CU")) : 1;   // (tuning)
+        if (ctx->d_bsk_hat_small && count <= (size_t)ctx->cu_count * (size_t)cu_max && launch_blind_rotate_cu(ctx, a, stream, &ctx->prof.kernel[1])) {
+            prof_end(ctx, 1, stream, e0, e1);
+            FBS_HIP(ctx, hipGetLastError());
+            return FBS_OK;
+        }
+    }
     const size_t whole = (p.log_n_poly == 10 && dig == 3) ? whole_cu_share(count, 4 * (size_t)ctx->cu_count) : 0;
     if (whole) {
         // the benchmark shape: four bootstraps = the eight waves of a CU in one workgroup

@@ -1,0 +1,265 @@
+// Blind rotation of ONE bootstrap on the eight waves of a CU: the shape of launches that leave most of the chip empty (a level
+// of a circuit cut across GPUs, a narrow level, the leftovers of a round).  gfx950 only; same arithmetic, same rounding rules
+// and the same ciphertexts as k_blind_rotate (fbs_blind_rotate.hip), word for word.
+//
+// A bootstrap's latency is n CMUX steps one after the other; inside a step the work is (k+1) l forward transforms, their
+// products with the key row, and k+1 inverse transforms.  The two-waves-per-bootstrap kernel runs those one after the other in
+// each wave (3 535 FP64-pipe instructions per wave and step at P1024: 4.8 ms per bootstrap however empty the chip is).  Here
+// the N = 1024 coefficients of a GLWE component are dealt over FOUR waves (4 coefficients per lane; component c = waves 4c ..
+// 4c+3), as in WavesNtt<10, 2>:
+//   * the first two Cooley-Tukey stages pair registers of one thread and leave four independent 256-point transforms hanging
+//     from nodes 4 .. 7 of the twiddle tree; ONE trip through LDS re-deals them so that wave w owns part w;
+//   * everything after that is private to a wave (PolyNtt<8, 6>: no workgroup barrier), and the l digit levels of a component
+//     go through it TOGETHER (fwd_from_multi): one re-deal, one twiddle fetch and one exchange per group for all levels, and
+//     2 l independent butterflies per stage to cover the FP64 pipe's latency where a single 4-coefficient transform has two;
+//   * products with the key row, hand-over of the partner component's half, private inverse transform, one re-deal back, the
+//     two joining stages, accumulate.
+// Four workgroup barriers per step (re-deal, hand-over, re-deal back, accumulator published for the next rotation) against
+// twelve when the generic kernel is instantiated with the four-wave transform (4.15 ms) and twenty-eight with round 2's
+// two-wave transform (4.8 ms).  The key copy is the one k_blind_rotate<10, 8, ...> uses (d_bsk_hat_small: evaluation order of
+// WavesNtt<10, 2>).
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "fbs_blind_rotate.hpp"
+
+namespace fbs {
+
+// NL: gadget levels (compile time: the levels' transforms are interleaved in registers); FIRST: what is known about the digits
+// (first_butterfly, fbs_ntt.hpp): 2 = beta <= 7, 1 = beta <= 9, 0 = nothing.
+#ifndef FBS_CU_WAVES_PER_EU
+#define FBS_CU_WAVES_PER_EU 2   // waves per SIMD the compiler must leave room for (4: two workgroups per CU, at most 128 registers per thread)
+#endif
+template <int LOGN, int NL, int FIRST>
+__global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(BrArgs a) {
+    using W = WavesNtt<LOGN, 2>;
+    using Part = typename W::Half;
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M;
+    static_assert(LANES == 256 && E >= 4 && W::EP * 4 == E, "four waves per polynomial");
+    // LDS (doubles): [2][N] accumulator as the next rotation reads it (the hand-over borrows it between two rotations);
+    // [2][NL][N] re-deal + private exchange buffers of the forward transforms (level 0's doubles for the inverse).
+    // 64 KB at N = 1024, NL = 3.
+    __shared__ double lds_all[2 * N + 2 * NL * N];
+    const uint32_t comp = threadIdx.x >> 8;          // GLWE component owned by this thread: 0 = mask, 1 = body
+    const uint32_t t = threadIdx.x & (LANES - 1);    // thread of the component
+    const uint32_t w = W::wave_of(t), ln = t & 63u;  // which part this wave owns; lane
+    double *accbuf = lds_all + comp * N;
+    double *accbuf_partner = lds_all + (comp ^ 1u) * N;
+    double *xbuf = lds_all + 2 * N + comp * (NL * N);
+    // twiddles: every transform this lane ever runs uses the same ones -- loaded once (the per-lane ones from the part's own
+    // table, the wave-uniform ones from the big tree at the part's root 4 + w)
+    const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
+    const typename Part::Tw twf = Part::load(a.tw_fwd + W::LANE_TABLE_OFFSET + w * M, big_f, 4u + w, ln);
+    const typename Part::Tw twi = Part::load(a.tw_inv + W::LANE_TABLE_OFFSET + w * M, big_i, 4u + w, ln);
+
+    const bool live = (size_t)blockIdx.x < a.count;
+    const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
+    size_t gate, ms_row;
+    gate_of(a.gv, f, &gate, &ms_row);
+    uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    if (table >= a.n_tables) table = 0;
+    const uint32_t *ms = a.ms + ms_row * (a.n + 1);
+    const uint64_t *tv = a.tvs + (size_t)table * N;
+    const uint32_t rows = 2 * NL;
+
+    // ACC = (0, X^{-b~} * TV), centred; register m of thread t = coefficient t + 256 m
+    double acc[E];
+    {
+        const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
+            const uint64_t v = tv[idx & (N - 1)];
+            acc[m] = comp ? fp_center(fp_from_u64((idx & N) ? fq_neg(v) : v)) : 0.0;
+        }
+    }
+    // rounding / digit constants: as in k_blind_rotate
+    const double round_scale = fp_exp2i(-(int)(FQ_BITS - NL * a.beta));
+    const uint32_t bhalf = 1u << (a.beta - 1);
+    double round_offset = 0.5 + fp_exp2i((int)(NL * a.beta));
+    uint32_t sign_bits = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < NL; j++) {
+        round_offset += (double)(bhalf << (j * a.beta));
+        sign_bits |= bhalf << (j * a.beta);
+    }
+    // cross-stage twiddles (wave-uniform, scalar registers for the whole rotation)
+    const double cw0 = big_f[1], cw1a = big_f[2], cw1b = big_f[3];
+    const double iw0 = big_i[1], iw1a = big_i[2], iw1b = big_i[3];
+    static_assert(E == 4, "the cross stages below are written out for four coefficients per thread");
+
+#pragma unroll
+    for (int m = 0; m < E; m++) accbuf[t + (uint32_t)LANES * m] = acc[m];
+    __syncthreads();
+
+    uint32_t r_next = ms[0];
+    for (uint32_t i = 0; i < a.n; i++) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
+        r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
+        if (r == 0) continue;   // X^0 * ACC - ACC = 0 (uniform over the workgroup: no barrier is skipped by part of it)
+
+        // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
+        // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
+        double2 ko[NL][E / 2], kt[NL][E / 2];
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++) {
+            const double *krow = a.bsk_hat + (((size_t)i * rows + comp * NL + lv) * 2) * N;
+            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
+            const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) {
+                ko[lv][j] = k_own[j * LANES + t];
+                kt[lv][j] = k_oth[j * LANES + t];
+            }
+        }
+
+        // ---- (X^r - 1) * ACC_c, centred, rounded to the closest multiple of q / B^l; packed balanced digits -------------
+        uint32_t digits[E];
+        {
+            const uint32_t from = (t - r) & (2u * N - 1u);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                const uint32_t idx = from + (uint32_t)LANES * m;   // < 3N: bit LOGN = sign, bits below = position
+                const double wv = accbuf[idx & (N - 1)];
+                const double v = __hiloint2double(__double2hiint(wv) ^ (int)((idx << (31 - LOGN)) & 0x80000000u), __double2loint(wv));
+                const double d = v - acc[m];
+                digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;
+            }
+        }
+
+        // ---- all levels: digits -> the two cross stages -> re-deal -> private transforms, together ------------------------
+        double x[NL][E];
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++) {
+            const uint32_t shift = ((uint32_t)NL - 1u - (uint32_t)lv) * a.beta;
+#pragma unroll
+            for (int m = 0; m < E; m++) x[lv][m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);
+            first_butterfly<FIRST>(x[lv][0], x[lv][2], cw0);
+            first_butterfly<FIRST>(x[lv][1], x[lv][3], cw0);
+            {
+                const double u = x[lv][0], v = fp_mulmod(x[lv][1], cw1a);
+                x[lv][0] = u + v;
+                x[lv][1] = u - v;
+            }
+            {
+                const double u = x[lv][2], v = fp_mulmod(x[lv][3], cw1b);
+                x[lv][2] = u + v;
+                x[lv][3] = u - v;
+            }
+            double *region = xbuf + lv * N;
+#pragma unroll
+            for (int q = 0; q < 4; q++) region[q * M + t] = x[lv][q];
+        }
+        __syncthreads();
+        double *bufs[NL];
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++) {
+            bufs[lv] = xbuf + lv * N + w * M;   // the words only this wave reads: its private exchange buffer from here on
+#pragma unroll
+            for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
+        }
+        Part::template forward_multi<NL, 0>(x, bufs, ln, twf, typename Part::NoHook{});
+
+        // ---- products with the key row: contributions to this component and to the partner's (lazy sums) ----------------
+        double own[E], other[E];
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++)
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) {
+                const double p0 = fp_mulmod(x[lv][2 * j], ko[lv][j].x), p1 = fp_mulmod(x[lv][2 * j + 1], ko[lv][j].y);
+                const double q0 = fp_mulmod(x[lv][2 * j], kt[lv][j].x), q1 = fp_mulmod(x[lv][2 * j + 1], kt[lv][j].y);
+                own[2 * j] = lv ? own[2 * j] + p0 : p0;
+                own[2 * j + 1] = lv ? own[2 * j + 1] + p1 : p1;
+                other[2 * j] = lv ? other[2 * j] + q0 : q0;
+                other[2 * j + 1] = lv ? other[2 * j + 1] + q1 : q1;
+            }
+
+        {
+            // ---- hand the partner its half (through the accumulator words: every rotation has read them by now) ---------
+#pragma unroll
+            for (int m = 0; m < E; m++) accbuf_partner[(uint32_t)LANES * m + t] = other[m];
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < E; m++) own[m] += accbuf[(uint32_t)LANES * m + t];
+            // ---- private inverse, re-deal back -----------------------------------------------------------------------
+            Part::inverse_one(own, bufs[0], ln, twi);
+            Part::sync();
+#pragma unroll
+            for (int m = 0; m < E; m++) bufs[0][ln + 64u * m] = own[m];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) own[q] = xbuf[q * M + t];
+        }
+        // ---- the two joining stages, accumulate -----------------------------------------------------------------------
+        {
+            {
+                const double u = own[0], v = own[1];
+                own[0] = u + v;
+                own[1] = fp_mulmod(u - v, iw1a);
+            }
+            {
+                const double u = own[2], v = own[3];
+                own[2] = u + v;
+                own[3] = fp_mulmod(u - v, iw1b);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                const double u = own[m], v = own[m + 2];
+                own[m] = u + v;
+                own[m + 2] = fp_mulmod(u - v, iw0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            acc[m] = fp_center(acc[m] + own[m]);
+            accbuf[t + (uint32_t)LANES * m] = acc[m];
+        }
+        __syncthreads();
+    }
+
+    // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
+    if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
+    uint64_t *out = gate_out(a.gv, f, a.ct_words);
+    if (comp == 0) {
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t j = t + (uint32_t)LANES * m;
+            const uint64_t v = fp_to_u64(fp_canon(acc[m]));
+            if (j == 0) out[0] = v;
+            else out[N - j] = fq_neg(v);
+        }
+    } else if (t == 0) {
+        out[N] = fq_add(fp_to_u64(fp_canon(acc[0])), a.post[table]);
+    }
+}
+
+bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
+    const fbs_params &p = ctx->p;
+    if (p.log_n_poly != 10 || ctx->group != 1 || !ctx->d_bsk_hat_small || p.l_bsk > 4) return false;
+    static const bool off = getenv("FBS_BR_NO_CU_KERNEL") != nullptr;   // (A/B switch: the generic kernel on the four-wave transform)
+    if (off) return false;
+    const int first = p.beta_bsk <= 7 ? 2 : p.beta_bsk <= 9 ? 1 : 0;
+    BrArgs b = a;
+    b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
+    const dim3 grid((unsigned)a.count), block(512);
+#define CU_CASE(NL, FIRST)                                                                       \
+    if (p.l_bsk == NL && first == FIRST) {                                                       \
+        *kernel = "k_blind_rotate_cu<10," #NL "," #FIRST ">";                                    \
+        hipLaunchKernelGGL((k_blind_rotate_cu<10, NL, FIRST>), grid, block, 0, stream, b);       \
+        return true;                                                                             \
+    }
+    CU_CASE(1, 0) CU_CASE(1, 1) CU_CASE(1, 2)
+    CU_CASE(2, 0) CU_CASE(2, 1) CU_CASE(2, 2)
+    CU_CASE(3, 0) CU_CASE(3, 1) CU_CASE(3, 2)
+    CU_CASE(4, 0) CU_CASE(4, 1) CU_CASE(4, 2)
+#undef CU_CASE
+    return false;
+}
+
+}  // namespace fbs

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "fbs_ntt.hpp"
+#include "fbs_ntt_lane.hpp"
 
 namespace fbs {
 
@@ -281,7 +282,10 @@ struct WavesNtt {
     // the wave-private transform of a part: the split schedule at 16 coefficients per lane; the plain grouped schedule at 4 or
     // 8 (N = 1024 or 2048 on four waves: one bootstrap on the eight waves of a CU, the shape of launches that leave most of
     // the chip empty)
-    using Half = typename std::conditional<E == 16, SplitNtt<(E == 16 ? LOGN - LOGW : 10), 6>, PolyNtt<LOGN - LOGW, 6>>::type;
+    // (N = 1024 on four waves: 256-point parts at 4 coefficients per lane, most of whose data movement is between registers and
+    // lanes -- LaneNtt256, fbs_ntt_lane.hpp)
+    using Half = typename std::conditional<E == 16, SplitNtt<(E == 16 ? LOGN - LOGW : 10), 6>,
+                                           typename std::conditional<E == 4 && M == 256, LaneNtt256, PolyNtt<LOGN - LOGW, 6>>::type>::type;
     static_assert((E == 16 || E == 8 || E == 4) && Half::E == E && E >= W && (LOGW == 1 || LOGW == 2), "two or four waves, 4, 8 or 16 coefficients per lane");
     // where the per-lane tables start inside the uploaded twiddle buffer: [N whole][N two halves][N four quarters]
     static constexpr int LANE_TABLE_OFFSET = LOGW * N;
