@@ -36,7 +36,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8.0 TB/s spec
 CLOCK_HZ = 2.4e9           # nominal engine clock
 SIMDS = 256 * 4            # 256 CUs x 4 SIMDs, one FP64 VALU wave-instruction per SIMD per 4 cycles
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_blind_rotate.json")   # counters of the timed kernel, collected offline
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_blind_rotate.json")   # counters of the timed kernel, collected offline
+BUTTERFLY_INSTR = 8        # exact 46-bit modular butterfly on the FP64 pipe: 6-instruction product, one add, one subtract
+MAC_INSTR = 7              # exact product + lazy accumulate
+
+
+def kernel_sources_sha256():
+    """What the offline PMC record must have been collected on: the kernel sources as they are now."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "tfhe_fbs_map_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()
 
 
 def parse_args(argv=None):
@@ -46,7 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=["batch", "circuit"], default="batch")
     ap.add_argument("--batch", type=int, default=1024, help="batch: independent FBS per GPU per step")
-    ap.add_argument("--mode", choices=["gate", "sample"], default="gate", help="circuit: what is cut across the ranks")
+    ap.add_argument("--mode", choices=["gate", "sample", "auto"], default="gate",
+                    help="circuit: what is cut across the ranks (auto: distributed.choose_sharding lays them out)")
+    ap.add_argument("--no-sharded-legs", action="store_true", help="batch, --gpus > 1: skip the gate- and sample-sharded circuit legs")
     ap.add_argument("--circuit", default="trivium_stream_v2__search_p15", help="circuit: fixture under tests/golden")
     ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
@@ -117,6 +133,10 @@ def worker(args):
         if dist is not None:
             dist.destroy_process_group()
         return 3
+    if args.workload == "batch" and world > 1 and not args.no_sharded_legs:
+        sharded = sharded_legs(rank, world, local, dist)              # every rank takes part; rank 0 holds the record
+        if rank == 0:
+            result["sharded"] = sharded
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
@@ -162,7 +182,9 @@ def params_record(prm):
                 log2_sigma_lwe_over_q=round(math.log2(prm.sigma_lwe / MODULUS), 2),
                 log2_sigma_glwe_over_q=round(math.log2(prm.sigma_glwe / MODULUS), 2),
                 security_bits_estimate=round(security_bits(prm), 1),
-                margin_sigmas_at_norm2_1=round(margin_sigmas(prm, 1), 2))
+                margin_sigmas_at_norm2_1=round(margin_sigmas(prm, 1), 2),
+                randomness="test-grade (ChaCha20 streams from a 64-bit benchmark seed, Irwin-Hall(12) noise): the security estimate "
+                           "is of the noise LEVELS; see tfhe_fbs_map_amd._native.RANDOMNESS_GRADE")
 
 
 def timed_batch(ctx, prm, B, rank, steps, warmup, dist, n_tables=16):  # noqa: C901
@@ -195,45 +217,104 @@ def timed_batch(ctx, prm, B, rank, steps, warmup, dist, n_tables=16):  # noqa: C
         step()
     fence(dist)
     elapsed = time.perf_counter() - t0
+    kernels = ctx.profile_kernels()
     prof = ctx.profile_read(reset=True)
+    prof["kernels"] = kernels
     ctx.profile(False)
     out = d_out.cpu().numpy().view(np.uint64)
     ok = bool(np.array_equal(ctx.decrypt(out), [tables[i][m] for i, m in zip(ids, msgs)]))
     return elapsed, prof, tables, cts, ids, msgs, out, ok
 
 
-def roofline_record(prm, prof, B):
+def algorithmic_instr_per_bootstrap(prm):
+    """per CMUX step (k+1) l forward and k+1 inverse transforms of N/2 log2 N butterflies and (k+1)^2 l N
+    pointwise multiply-accumulates (55.3 k modular products at P1024), priced at what this arithmetic costs on the FP64 pipe
+    (8 instructions per butterfly, 7 per MAC), in wave-instructions (64 lanes).  Two key bits per step: half the steps, and
+    the 3 (k+1)^2 l N bundle products on top."""
+    N, k, l = prm.N, prm.k, prm.l_bsk
+    butterflies = ((k + 1) * l + (k + 1)) * (N // 2) * prm.log_n_poly
+    macs = (k + 1) ** 2 * l * N
+    steps = prm.n
+    if prm.bsk_group == 2:
+        steps = prm.n // 2
+        macs += 3 * (k + 1) ** 2 * l * N
+    return steps * (butterflies * BUTTERFLY_INSTR + macs * MAC_INSTR) / 64.0
+
+
+def roofline_record(prm, prof, kernels, B, steps):
     """The dominant kernel is the blind rotation.  It is bound by FP64 VALU issue, not by HBM: every workgroup walks the
     bootstrapping key in step, so after the first touch the key comes out of L2 / Infinity Cache (PMC: a few % of the
-    algorithmic bytes reach the fabric).  `frac` is therefore the fraction of the chip's FP64 issue slots the kernel
-    fills: VALU wave-instructions per launch (PMC SQ_INSTS_VALU, collected offline with rocprofv3 on this very
-    command, profiles/r02/) x 4 cycles / (1024 SIMDs x 2.4 GHz) / the average launch time measured live here."""
-    br, ks = prof["blind_rotate"], prof["keyswitch"]
-    br_ms = br["ms"] / max(1, br["launches"])
+    algorithmic bytes reach the fabric).
+      achieved / frac (= algorithmic_frac): the ALGORITHMIC work (`algorithmic_instr_per_bootstrap`, SURVEY 8(d)(ii) x the
+          instruction price of this arithmetic) per launch / the launch time measured live here with HIP events on the
+          launch stream / the chip's FP64 issue rate (1024 SIMDs x 2.4 GHz / 4 cycles).
+      valu_frac: issue-slot OCCUPANCY -- VALU wave-instructions the kernel actually executed (PMC SQ_INSTS_VALU, collected
+          offline with rocprofv3 on this command: profiles/r03/) x 4 cycles over the same time; issue_cycle_frac charges the
+          32-bit ones 2 cycles (MI355X_MICROARCH.md: v_fma_f32 2 cycles with two waves on a SIMD) where the record has the mix.
+          Both null when the record was collected on other kernel sources than the ones timed (csrc hash).
+      key_stream_vs_hbm_peak: SURVEY 8(d)'s contract bytes (every key row once per bootstrap) over the time over 8 TB/s -- NOT
+          a utilisation (the key stream does not come from HBM; the figure passes 1 on the whole path); fabric_GBps is what
+          reached the fabric (PMC FETCH_SIZE x2 + WRITE_SIZE)."""
+    ks = prof["keyswitch"]
     ks_ms = ks["ms"] / max(1, ks["launches"])
+    br_all = {k: v for k, v in kernels.items() if v["kind"] == "blind_rotate"}
+    if not br_all:
+        return None
+    name = max(br_all, key=lambda k: br_all[k]["ms"])
+    br = br_all[name]
+    br_ms = br["ms"] / max(1, br["launches"])
     N, n, k = prm.N, prm.n, prm.k
-    # algorithmic bytes of ONE blind-rotation launch: per FBS every bootstrapping-key row once, the test vector, the
-    # mod-switched input and the extracted output; SURVEY 8(d)'s whole-FBS figure (103 309 328 B at P1024)
-    # additionally holds the key-switching key, which is the other kernel's
-    br_bytes_per_fbs = n * (k + 1) * prm.l_bsk * (k + 1) * N * 8 + N * 8 + (n + 1) * 4 + (k * N + 1) * 8
-    rec = dict(bound="fp64_valu", kernel=br["kernel"], unit="VALU wave-instr/s", avg_launch_ms=br_ms, units_per_launch=B,
-               peak=SIMDS * CLOCK_HZ / 4.0, achieved=None, frac=None, valu_frac=None, traffic=None,
-               hbm_algorithmic_frac=br_bytes_per_fbs * B / (br_ms * 1e-3) / HBM_PEAK,
-               hbm_algorithmic_bytes_per_fbs=br_bytes_per_fbs, hbm_algorithmic_GBps=br_bytes_per_fbs * B / (br_ms * 1e-3) / 1e9,
+    # a launch the launcher cuts (whole rounds as four-bootstrap workgroups + the leftovers in another shape) shows as two
+    # kernels: each is reported with its own time, and the dominant one is priced on the bootstraps IT ran
+    per_round = 4 * 256
+    if len(br_all) == 1:
+        units = B
+    elif name == "k_blind_rotate<10,6,3,4>":
+        units = B - B % per_round
+    else:
+        units = B % per_round
+    peak = SIMDS * CLOCK_HZ / 4.0
+    algo = algorithmic_instr_per_bootstrap(prm) * units
+    ggsw = (prm.n // 2 * 3 if prm.bsk_group == 2 else n) * (k + 1) * prm.l_bsk * (k + 1) * N * 8
+    br_bytes_per_fbs = ggsw + N * 8 + (n + 1) * 4 + (k * N + 1) * 8
+    rec = dict(bound="fp64_valu", kernel=name, unit="VALU wave-instr/s", avg_launch_ms=br_ms, units_per_launch=units, peak=peak,
+               achieved=algo / (br_ms * 1e-3), frac=algo / (br_ms * 1e-3) / peak, algorithmic_frac=algo / (br_ms * 1e-3) / peak,
+               algorithmic_instr_per_bootstrap_step=algorithmic_instr_per_bootstrap(prm) / (n if prm.bsk_group != 2 else n // 2),
+               algorithmic_formula="steps x ([(k+1) l + (k+1)] N/2 log2 N butterflies x %d + (k+1)^2 l N MACs x %d) / 64 lanes" % (BUTTERFLY_INSTR, MAC_INSTR),
+               valu_frac=None, issue_cycle_frac=None, traffic=None, fabric_GBps=None,
+               launches=[dict(kernel=kn, launches_per_step=v["launches"] / max(1, steps), avg_launch_ms=v["ms"] / max(1, v["launches"]))
+                         for kn, v in sorted(br_all.items(), key=lambda kv: -kv[1]["ms"])],
+               key_stream_vs_hbm_peak=br_bytes_per_fbs * units / (br_ms * 1e-3) / HBM_PEAK,
+               key_stream_bytes_per_fbs=br_bytes_per_fbs,
                keyswitch_kernel=ks["kernel"], keyswitch_avg_launch_ms=ks_ms,
-               note="bound by FP64 VALU issue (one wave-instruction per SIMD per 4 cycles at the nominal 2.4 GHz); "
-                    "hbm_algorithmic_* count every key row once per bootstrap as SURVEY 8(d) prescribes, but the key is served "
-                    "from L2/Infinity Cache after first touch: `traffic` is what reached the fabric")
+               note="bound by FP64 VALU issue (one wave-instruction per SIMD per 4 cycles at the nominal 2.4 GHz); frac = algorithmic "
+                    "work over time over that peak, valu_frac = executed instructions over the same (occupancy); "
+                    "key_stream_vs_hbm_peak counts every key row once per bootstrap as SURVEY 8(d) prescribes and is not a utilisation: "
+                    "the key is served from L2/Infinity Cache after first touch, `traffic` is what reached the fabric")
+    pmc = None
     if os.path.exists(PMC_FILE):
-        pmc = json.load(open(PMC_FILE)).get(br["kernel"])
-        if pmc and pmc.get("units_per_launch") == B and pmc.get("n") == n:
-            insts = pmc["SQ_INSTS_VALU_per_launch"]
-            rec["achieved"] = insts / (br_ms * 1e-3)
-            rec["valu_frac"] = rec["frac"] = rec["achieved"] / rec["peak"]
-            rec["valu_insts_per_launch"] = insts
-            rec["valu_insts_per_wave_per_step"] = pmc.get("valu_per_wave_per_step")
-            rec["traffic"] = pmc.get("hbm_bytes_per_launch")          # bytes per launch, FETCH_SIZE x2 + WRITE_SIZE
-            rec["traffic_source"] = "%s; collected offline in separate rocprofv3 --pmc passes of this command, not in this run" % pmc.get("source")
+        pmc = json.load(open(PMC_FILE)).get(name)
+    if pmc is None:
+        rec["pmc"] = "no record for %s in %s" % (name, os.path.relpath(PMC_FILE, ROOT))
+    elif pmc.get("csrc_sha256") != kernel_sources_sha256():
+        rec["pmc"] = "stale: %s was collected on other kernel sources (csrc sha256 %s..., now %s...); re-run tools/profile_round.sh" % (
+            os.path.relpath(PMC_FILE, ROOT), str(pmc.get("csrc_sha256"))[:12], kernel_sources_sha256()[:12])
+    elif pmc.get("units_per_launch") != units or pmc.get("n") != n:
+        rec["pmc"] = "record is for %s bootstraps per launch at n = %s" % (pmc.get("units_per_launch"), pmc.get("n"))
+    else:
+        insts = pmc["SQ_INSTS_VALU_per_launch"]
+        rec["valu_frac"] = insts / (br_ms * 1e-3) / peak
+        rec["valu_insts_per_launch"] = insts
+        rec["valu_insts_per_wave_per_step"] = pmc.get("valu_per_wave_per_step")
+        if pmc.get("valu_64bit_per_launch") is not None:
+            cycles = 4.0 * pmc["valu_64bit_per_launch"] + 2.0 * (insts - pmc["valu_64bit_per_launch"])
+            rec["issue_cycle_frac"] = cycles / (br_ms * 1e-3) / (SIMDS * CLOCK_HZ)
+            rec["valu_64bit_share"] = pmc["valu_64bit_per_launch"] / insts
+        rec["traffic"] = pmc.get("hbm_bytes_per_launch")          # bytes per launch, FETCH_SIZE x2 + WRITE_SIZE
+        if rec["traffic"]:
+            rec["fabric_GBps"] = rec["traffic"] / (br_ms * 1e-3) / 1e9
+        rec["pmc"] = "%s; collected offline in separate rocprofv3 --pmc passes of this command on these kernel sources, not in this run" % pmc.get("source")
+        rec["traffic_source"] = rec["pmc"]
     return rec
 
 
@@ -259,7 +340,7 @@ def run_batch(args, rank, world, local, dist):
                                        "(a kernel benchmark shape, not a secure configuration: see `params` and `secure`)" % B,
                               batch_per_gpu=B, parallelism="replicas of the batch per GPU, keys replicated, no collective",
                               device=ctx.device_info, params=params_record(prm)),
-                  decrypt_ok=ok, roofline=roofline_record(prm, prof, B))
+                  decrypt_ok=ok, roofline=roofline_record(prm, prof, prof["kernels"], B, args.steps))
     if world == 1 and args.cpu_sample != 0:
         result["cpu_baseline"] = cpu_baseline(prm, tables, cts, ids, out, args.cpu_sample)
     ctx.close()
@@ -267,6 +348,65 @@ def run_batch(args, rank, world, local, dist):
         result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
         result["shared_rotations"] = shared_rotations_leg(local)
     return result
+
+
+def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p15", T=64):
+    """--gpus N > 1: north_star's multi-GPU shape next to the weak-scaling headline, in the same line -- one whole mapped program
+    (BASELINE configs[3] stand-in) on T samples, STRONG scaling, cut three ways by distributed.ShardedRunner: gate-sharded (every
+    level's (gate, sample) batch over all ranks, one RCCL all-gather per level), sample-sharded (no data-path collective) and
+    the layout distributed.choose_sharding picks.  Every rank calls this (collectives inside); rank 0 returns the record."""
+    import gzip
+    import numpy as np
+    import torch
+    from tfhe_fbs_map_amd import Context, Program, params_for, parse_fbs
+    from tfhe_fbs_map_amd.distributed import GpuBackend, ShardedRunner, choose_sharding
+    with gzip.open(os.path.join(ROOT, "tests", "golden", circuit + ".json.gz"), "rb") as f:
+        rec = json.loads(f.read().decode())
+    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+    low = env.lower()
+    prm = params_for(int(circuit.rsplit("_p", 1)[-1]))
+    ctx = Context(prm, seed=1, device=local)
+    prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                   low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    bits = np.random.default_rng(42).integers(0, 2, (prog.n_inputs, T))
+    clear = cleartext(low, bits)
+    d_in = torch.from_numpy(ctx.encrypt(bits, nonce0=0).view(np.int64)).cuda()
+    ctx.reserve(max_keyswitches=prog.max_width * T)
+    pick = choose_sharding(list(prog.level_width), T, world)
+    legs = {}
+    for label, gs in (("gate", 1), ("sample", world if T >= world else None), ("chosen", pick["sample_groups"])):
+        if gs is None or (label == "chosen" and any(v["sample_groups"] == gs for v in legs.values())):
+            continue
+        runner = ShardedRunner(GpuBackend(prog), sample_groups=gs)
+        runner.time_collectives = True
+        runner.run_local(d_in, T)                                     # warm-up (buffers, every launch shape)
+        runner.collective_ms()
+        before = runner.collectives
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        fence(dist)
+        t0 = time.perf_counter()
+        out, s0, s1 = runner.run_local(d_in, T)
+        fence(dist)
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist)
+        kernels = ctx.profile_kernels()
+        prof = ctx.profile_read(reset=True)
+        ctx.profile(False)
+        got = ctx.decrypt(out.cpu().numpy().view(np.uint64))
+        ok = all(np.array_equal(got[k][:s1 - s0], clear[k][s0:s1]) for k, w in enumerate(low["out_wire"]) if w >= 0)
+        legs[label] = dict(sample_groups=gs, gate_groups=world // gs, rccl_ranks=world, seconds=elapsed,
+                           value=prog.n_bootstrap * T / elapsed, unit="FBS/s", scaling="strong",
+                           collectives_per_step=runner.collectives - before, allgather_ms_rank0=runner.collective_ms(),
+                           kernels_ms_rank0={k: v["ms"] for k, v in prof.items()},
+                           kernel_instantiations_rank0={k: dict(launches=v["launches"], ms=round(v["ms"], 3)) for k, v in kernels.items()},
+                           decrypt_ok=all_ok(ok, dist))
+    ctx.close()
+    if rank != 0:
+        return None
+    return dict(workload="%s (reference mapper output, %d bootstraps, depth %d, widest level %d) on %d samples, reduced-noise benchmark set, "
+                         "one evaluation per layout" % (circuit, prog.n_bootstrap, prog.depth, prog.max_width, T),
+                choose_sharding=dict(sample_groups=pick["sample_groups"], gate_groups=pick["gate_groups"],
+                                     predicted_speedup_over_one_gpu=round(pick["predicted_speedup"], 2)), legs=legs)
 
 
 def secure_leg(B, local, steps):
@@ -280,7 +420,10 @@ def secure_leg(B, local, steps):
         ctx = Context(prm, seed=1, device=local)
         elapsed, prof, *_, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
         br, ks = prof["blind_rotate"], prof["keyswitch"]
+        roof = roofline_record(prm, prof, prof["kernels"], B, steps)
         rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok, params=params_record(prm),
+                   roofline={k: roof[k] for k in ("kernel", "avg_launch_ms", "frac", "algorithmic_frac", "valu_frac", "issue_cycle_frac",
+                                                  "fabric_GBps", "pmc")} if roof else None,
                    margin_sigmas_at_norm2_70=round(margin_sigmas(prm, 70), 2), modelled_cost_vs_p1024=round(bootstrap_cost(prm), 3),
                    blind_rotate_kernel=br["kernel"], blind_rotate_avg_launch_ms=br["ms"] / max(1, br["launches"]),
                    keyswitch_avg_launch_ms=ks["ms"] / max(1, ks["launches"]))
@@ -417,9 +560,21 @@ def run_circuit(args, rank, world, local, dist):
     clear = cleartext(low, bits)
     d_in = torch.from_numpy(ctx.encrypt(bits, nonce0=0).view(np.int64)).cuda()
     collectives = lambda: 0                                                          # noqa: E731
+    window = (0, T)
+    layout = dict(sample_groups=1, gate_groups=world) if args.mode == "gate" else dict(sample_groups=world, gate_groups=1)
     if args.mode == "gate":
         runner = GateShardedRunner(GpuBackend(prog))
         step = lambda: runner.run_device(d_in, T)                                   # noqa: E731
+        collectives = lambda: runner.collectives                                    # noqa: E731
+    elif args.mode == "auto":
+        # the layout choose_sharding prices cheapest for this program, T and world: sample groups x gate groups (strong scaling)
+        from tfhe_fbs_map_amd.distributed import ShardedRunner, choose_sharding
+        pick = choose_sharding(list(prog.level_width), T, world)
+        layout = dict(sample_groups=pick["sample_groups"], gate_groups=pick["gate_groups"],
+                      predicted_speedup_over_one_gpu=round(pick["predicted_speedup"], 2))
+        runner = ShardedRunner(GpuBackend(prog), sample_groups=pick["sample_groups"])
+        window = split_window(T, pick["sample_groups"], rank // pick["gate_groups"])
+        step = lambda: runner.run_local(d_in, T)[0]                                 # noqa: E731
         collectives = lambda: runner.collectives                                    # noqa: E731
     else:
         # sample-sharded: the rank's share IS the whole program on its own samples -- one device-side call, no exchange
@@ -441,7 +596,7 @@ def run_circuit(args, rank, world, local, dist):
     elapsed = max_over_ranks(time.perf_counter() - t0, dist)
     prof = ctx.profile_read(reset=True)
     got = ctx.decrypt(out.cpu().numpy().view(np.uint64))
-    ok = all(np.array_equal(got[k], clear[k]) for k, w in enumerate(low["out_wire"]) if w >= 0)
+    ok = all(np.array_equal(got[k][:window[1] - window[0]], clear[k][window[0]:window[1]]) for k, w in enumerate(low["out_wire"]) if w >= 0)
     ok = all_ok(ok, dist)
     if rank != 0:
         return None
@@ -449,19 +604,25 @@ def run_circuit(args, rank, world, local, dist):
     value = fbs_per_eval * args.steps / elapsed
     return dict(metric="functional bootstraps/sec (batched), N=1024", value=value, unit="FBS/s", n_gpus=world, steps=args.steps,
                 warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-                scaling="strong" if args.mode == "gate" else "weak", vs_baseline=None,
+                scaling="weak" if args.mode == "sample" else "strong", vs_baseline=None,
                 dtype="f64 (exact integer arithmetic mod a 46-bit prime via FMA; residues in 64-bit words)", data="synthetic",
                 config=dict(workload="BASELINE configs[3] stand-in: %s (reference mapper output, %d bootstraps, depth %d, widest level %d) "
                                      "on %d samples%s, %s" % (args.circuit, prog.n_bootstrap, prog.depth, prog.max_width, T,
                                                                               " per rank" if args.mode == "sample" else "",
                                                                               "128-bit set chosen for its (p, norm2)" if args.secure else "reduced-noise benchmark set"),
-                            mode=args.mode, rccl_ranks=world, collectives_per_step=collectives() // max(1, args.steps + args.warmup),
+                            mode=args.mode, layout=layout, rccl_ranks=world, collectives_per_step=collectives() // max(1, args.steps + args.warmup),
                             parallelism=("levels cut across ranks, one all-gather per level" if args.mode == "gate" else
-                                         "samples cut across ranks, no data-path collective"),
+                                         "samples cut across ranks, no data-path collective" if args.mode == "sample" else
+                                         "sample groups x gate groups as distributed.choose_sharding lays them out"),
                             wire_slots=prog.n_slots, wires=prog.n_inputs + len(low["kind"]), key_switches=prog.n_keyswitch,
                             norm2_linprod=stats["norm2_linprod"], device=ctx.device_info, params=params_record(prm)),
                 decrypt_ok=ok,
                 kernels_ms_per_step={k: v["ms"] / args.steps for k, v in prof.items()})
+
+
+def split_window(T, parts, r):
+    chunk = -(-T // parts)
+    return min(T, r * chunk), min(T, (r + 1) * chunk)
 
 
 def cleartext(low, bits):

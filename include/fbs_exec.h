@@ -24,9 +24,11 @@
  * (map_circuit.py:97,117-122).
  *
  * Streams.  Entry points that take a `stream` queue their work on it and return
- * without waiting.  All calls on a context share its scratch buffers: calls on
- * one stream are ordered by the stream, and a call on a different stream first
- * waits (on the device) for the previous call that used the scratch.
+ * without waiting -- except a call that needs more scratch than any earlier one,
+ * which blocks while the scratch grows (fbs_ctx_reserve sizes it up front).  All
+ * calls on a context share its scratch buffers: calls on one stream are ordered
+ * by the stream, and a call on a different stream first waits (on the device)
+ * for the previous call that used the scratch.
  */
 #ifndef FBS_EXEC_H
 #define FBS_EXEC_H
@@ -78,9 +80,40 @@ typedef struct fbs_prog fbs_prog;
 
 /* ---- context ------------------------------------------------------------ */
 /* device: HIP ordinal.  seed: all key material and encryption randomness is
- * derived from it (ChaCha20 streams, DESIGN.md "Randomness"). */
+ * derived from it (ChaCha20 streams, DESIGN.md "Randomness").
+ *
+ * RANDOMNESS GRADE.  fbs_ctx_create is the REPRODUCIBLE form: 64 bits of seed, the
+ * same keys for the same seed whatever the parameter set -- for tests, benchmarks
+ * and checkers that must be keyed identically (oracle/).  It is not a way to make
+ * production keys, whatever noise the parameter set carries.  fbs_ctx_create_seeded
+ * keys the generator with 32 caller-supplied bytes (e.g. from the OS) and mixes the
+ * parameter set into the derivation, so that two parameter sets under one seed
+ * share no key material.  In BOTH forms the noise sampler is an integer
+ * Irwin-Hall(12) stand-in for a discrete Gaussian (bounded at 6 sigma): test-grade.
+ * A deployment that needs more brings its own keys with fbs_import_keys. */
 int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out);
+int fbs_ctx_create_seeded(const fbs_params *params, const uint8_t seed[32], int device, fbs_ctx **out);
 void fbs_ctx_destroy(fbs_ctx *ctx);
+/* Scratch (modulus-switched rows, the key switch's digit/limb buffers, accumulators of shared rotations, the wire
+ * buffer of fbs_eval) grows on demand, and growing BLOCKS: the call that needs more than any earlier one waits for
+ * the context's queued work, frees and reallocates.  A host that wants every *_dev call to be kernel launches and
+ * nothing else (several streams, collectives between levels) sizes it once: max_keyswitches = the largest number
+ * of key switches one call will ask for (fbs_bootstrap_batch_dev: count; fbs_level_bootstrap_dev: the slice's
+ * sources x samples; fbs_eval_dev: fbs_layout.max_sources x T), max_shared_rows = shared rotations x samples of a
+ * fused program's widest level (0 otherwise), wire_words = n_slots x T x (D+1) for fbs_eval_dev (0 otherwise).
+ * Zero leaves a buffer as it is.  After it, the only blocking case left is a call that exceeds what was reserved. */
+int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows, size_t wire_words);
+/* Launcher knobs -- which kernel shape a launch takes.  The defaults are the measured choices; tests set them to reach
+ * every launcher branch in one process, tools/ to time one shape against another.  Results never depend on them.
+ *   "ks_gemm_min" (1)  key switches per launch from which the int8 GEMM on the matrix cores is used
+ *   "ks_mfma" (1), "ks_fp" (1), "ks_cols_major" (1), "ks_split" (0 = automatic)   key-switch fallbacks / grid order
+ *   "br_whole_cu" (1)       whole rounds of a launch as one four-bootstrap workgroup per CU
+ *   "br_cu_kernel" (1)      launches that leave most of the chip empty as ONE bootstrap per CU (eight waves)
+ *   "br_cu_max_per_cu" (2)  ... up to this many bootstraps per CU */
+int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value);
+/* counters: "scratch_growths" (how often a call (re)allocated scratch, i.e. blocked), "ms_capacity", "acc_capacity",
+ * "wires_capacity", "next_nonce", "cu_count" */
+int fbs_ctx_stat(const fbs_ctx *ctx, const char *name, int64_t *value);
 /* text of the last failure on `ctx` (or of the last failed fbs_ctx_create when ctx == NULL) */
 const char *fbs_last_error(const fbs_ctx *ctx);
 /* "gfx950 <device name> CUs=<n>" of the bound device */
@@ -97,12 +130,21 @@ int fbs_keygen(fbs_ctx *ctx);
 int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]);
 /* test hook: copy keys out (any pointer may be NULL) so a checker can be keyed identically */
 int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk);
+/* The mirror: keys made elsewhere (a caller's own CSPRNG and Gaussian sampler, or a checker's) in the layout of
+ * fbs_key_sizes, instead of fbs_keygen.  Secret keys are binary, every other word a canonical residue (< q); the
+ * evaluation keys must encrypt the secrets under this library's gadget conventions (GGSW row
+ * (c, l) = GLWE(0) + s g_l on component c, g_l = round(q / 2^(beta (l+1))); key-switching row (j, v) = LWE(s_j h_v)).
+ * The secret keys stay on the host and serve fbs_encrypt / fbs_decrypt only. */
+int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk, const uint64_t *ksk);
 
 /* ---- encrypt / decrypt (host side, big key) ------------------------------
  * Stand behind the Input arm of eval (fbs_exec_env.py:213-214) and the final
  * read-out (:225-229).  Ciphertext i draws its randomness from stream
  * nonce0 + i, so a run is reproducible. cts: [count][D+1]. */
 int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts);
+/* The same on streams nobody has used: the context keeps a counter over [2^55, 2^56) (fbs_encrypt's explicit nonces stay
+ * below 2^55), so two calls never share mask or noise.  *nonce0 (may be NULL) = the first stream this call took. */
+int fbs_encrypt_fresh(fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t *cts, uint64_t *nonce0);
 /* msgs[i] = round(phase * 2p / q) mod 2p */
 int fbs_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);
 
@@ -237,6 +279,13 @@ int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset
 /* name of the kernel instantiation the most recent launch of kind `which` (0, 1, 2 as above) used: the launcher
  * picks the shape by parameter set and batch size */
 const char *fbs_profile_kernel(const fbs_ctx *ctx, int which);
+/* The same totals per kernel instantiation since the last reset (fbs_profile_read with reset clears them too): lines
+ * "<kind>\t<kernel>\t<launches>\t<ms>\n", kind = 0, 1, 2 as above.  A launch the launcher cuts into a whole-round part and
+ * a remainder shows as two entries.  *needed (may be NULL) = bytes the text takes; buf == NULL only asks for that. */
+int fbs_profile_kernels(fbs_ctx *ctx, char *buf, size_t cap, size_t *needed);
+/* newline-separated names of every key-switch and blind-rotation kernel instantiation the launchers can pick, by the
+ * rules of their dispatch: what tests/test_gpu_dispatch.py drives one by one against the oracle */
+const char *fbs_kernel_catalog(void);
 /* block until all work queued on the context's stream (or `stream`) has finished */
 int fbs_sync(fbs_ctx *ctx, void *stream);
 

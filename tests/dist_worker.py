@@ -84,7 +84,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     from tfhe_fbs_map_amd import Params, parse_fbs
-    from tfhe_fbs_map_amd.distributed import GateShardedRunner, SampleShardedRunner
+    from tfhe_fbs_map_amd.distributed import GateShardedRunner, SampleShardedRunner, ShardedRunner
     rec = load_fixture(name)
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     low = env.lower()
@@ -94,7 +94,10 @@ def main():
     ins, expect = subsample(rec, T)
     cts = np.stack([o.encrypt(ins[n], nonce0=100 * i) for i, n in enumerate(low["input_names"])])
     res = {}
-    for mode, cls in (("gate", GateShardedRunner), ("sample", SampleShardedRunner)):
+    modes = [("gate", GateShardedRunner), ("sample", SampleShardedRunner)]
+    if world == 4:                                        # two sample groups of two gate-sharding ranks each
+        modes.append(("grid", lambda be: ShardedRunner(be, sample_groups=2)))
+    for mode, cls in modes:
         be = OracleBackend(o, low)
         runner = cls(be)
         out = runner.run(cts, T)
@@ -109,7 +112,8 @@ def main():
         dec = np.stack([o.decrypt(res["gate"][k]) for k in range(len(outs))])
         np.savez(out_path, gate=res["gate"], sample=res["sample"], ref=ref, dec=dec,
                  gate_collectives=res["gate_collectives"], sample_collectives=res["sample_collectives"],
-                 gate_fbs=res["gate_fbs_done"], sample_fbs=res["sample_fbs_done"], world=world)
+                 gate_fbs=res["gate_fbs_done"], sample_fbs=res["sample_fbs_done"], world=world,
+                 **({"grid": res["grid"], "grid_collectives": res["grid_collectives"], "grid_fbs": res["grid_fbs_done"]} if world == 4 else {}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -10,7 +10,7 @@ import pytest
 
 from tests.helpers import load_fixture, subsample
 from tfhe_fbs_map_amd import parse_fbs
-from tfhe_fbs_map_amd.distributed import plan_levels, split_range
+from tfhe_fbs_map_amd.distributed import choose_sharding, launch_ms, plan_levels, split_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,7 +40,8 @@ def test_plan_matches_facade_schedule():
             done |= set(plan["boot"][L]["dst"])
 
 
-@pytest.mark.parametrize("name,T", [("full_adder__search_p7", 5), ("adder8__search_p7", 3), ("edge_outputs", 4)])
+@pytest.mark.parametrize("name,T", [("full_adder__search_p7", 5), ("adder8__search_p7", 3), ("edge_outputs", 4),
+                                    ("full_adder__search_p7", 1)])        # T = 1: levels narrower than the world, empty slices
 def test_two_ranks_bit_identical(tmp_path, name, T):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")
@@ -65,3 +66,45 @@ def test_two_ranks_bit_identical(tmp_path, name, T):
     assert int(z["sample_collectives"]) == 1                      # only the final gather of outputs
     total = sum(widths) * T
     assert int(z["gate_fbs"]) <= -(-total // 2) + depth * 1 and int(z["gate_fbs"]) >= total // 2 - depth
+
+
+def test_four_ranks_as_two_sample_groups_of_two_gate_ranks(tmp_path):
+    """The 2-D layout `choose_sharding` can ask for: ranks 0, 1 cut the levels of samples [0, 3), ranks 2, 3 those of samples
+    [3, 5); one all-gather per level inside each pair, one gather of the outputs over all four at the end."""
+    name, T = "full_adder__search_p7", 5
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="4", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), name, str(T), out],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(4)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    z = np.load(out)
+    rec = load_fixture(name)
+    env_ = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+    low = env_.lower()
+    _, depth, widths = env_.schedule()
+    assert int(z["world"]) == 4
+    for k, w in enumerate(low["out_wire"]):
+        if w >= 0:
+            for mode in ("gate", "sample", "grid"):
+                assert np.array_equal(z[mode][k], z["ref"][k]), mode
+    assert int(z["grid_collectives"]) == depth + 1
+    assert int(z["grid_fbs"]) <= -(-sum(widths) * 3 // 2) + depth          # rank 0: half of the levels of three samples
+
+
+def test_choose_sharding_prefers_samples_and_falls_back_to_gates():
+    """Samples are cut first (no collectives); gate groups appear when there are fewer samples than ranks; the prediction is
+    the launch-time staircase summed over the levels."""
+    widths = [3, 1, 2, 13, 8]
+    c = choose_sharding(widths, 1000, 8)
+    assert (c["sample_groups"], c["gate_groups"]) == (8, 1)
+    assert abs(c["predicted_ms"] - sum(launch_ms(w * 125) for w in widths)) < 1e-9
+    assert c["single_gpu_ms"] > c["predicted_ms"] and 1.0 < c["predicted_speedup"] <= 8.0
+    c = choose_sharding(widths, 2, 8)
+    assert (c["sample_groups"], c["gate_groups"]) == (2, 4)
+    c = choose_sharding([400, 300], 1, 4)
+    assert (c["sample_groups"], c["gate_groups"]) == (1, 4) and c["predicted_speedup"] > 1.5
+    assert {(k["sample_groups"], k["gate_groups"]) for k in choose_sharding(widths, 64, 8)["candidates"]} == {(1, 8), (2, 4), (4, 2), (8, 1)}
+    # the staircase: one more bootstrap than a CU-round costs a second round; whole rounds of 1024 add up
+    assert launch_ms(257) > 1.7 * launch_ms(256) and launch_ms(4096) < 4.2 * launch_ms(1024)

@@ -184,16 +184,27 @@ def test_trivium_levels_are_wide():
     assert depth <= 8 and max(widths) >= 60
 
 
-def test_exec_config_hands_out_fresh_nonces_and_a_random_seed():
-    """No GPU needed: every ciphertext encrypted under one ExecConfig gets its own randomness stream, and the key seed is
-    not a constant unless the caller makes it one."""
+def test_exec_config_seeds_and_nonces():
+    """No GPU needed: the key seed is 32 fresh bytes unless the caller makes it a constant, and encryption streams are the
+    context's own counter (fbs_encrypt_fresh) unless the caller pins them."""
     from tfhe_fbs_map_amd import ExecConfig
     cfg = ExecConfig()
-    assert cfg.take_nonces(12) == 0 and cfg.take_nonces(5) == 12 and cfg.take_nonces(1) == 17
+    assert cfg.take_nonces(12) is None                       # None -> Context.encrypt(nonce0=None) -> fbs_encrypt_fresh
     a, b = ExecConfig().key_seed(), ExecConfig().key_seed()
-    assert a != b and cfg.key_seed() == cfg.key_seed()
+    assert isinstance(a, bytes) and len(a) == 32 and a != b and cfg.key_seed() == cfg.key_seed()
     fixed = ExecConfig(seed=7, nonce0=100)
     assert fixed.key_seed() == 7 and fixed.take_nonces(9) == 100 and fixed.take_nonces(9) == 100     # explicit = reproducible
+
+
+def test_margin_floor_is_opt_in():
+    """Where nothing reaches the asked margin the selector raises and says how to relax; it steps down only when told to."""
+    import pytest
+    from tfhe_fbs_map_amd import ExecConfig
+    from tfhe_fbs_map_amd.params import margin_sigmas
+    with pytest.raises(ValueError, match="allow_margin_floor"):
+        ExecConfig(min_margin=40.0).params_choice(15, 70)
+    prm = ExecConfig(min_margin=40.0, allow_margin_floor=4.0).params_choice(15, 70)
+    assert 4.0 <= margin_sigmas(prm, 70) < 40.0
 
 
 def test_fusion_statistics_of_a_one_gate_one_bootstrap_program():

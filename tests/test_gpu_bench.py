@@ -27,9 +27,14 @@ def test_headline_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "FBS/s" and d["vs_baseline"] is None and d["decrypt_ok"]
     assert abs(d["value"] - 256 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "fp64_valu" and r["kernel"].startswith("k_blind_rotate<10,") and r["avg_launch_ms"] > 0
-    assert 0 < r["hbm_algorithmic_frac"] and "whole_path_frac" not in r
-    assert r["traffic"] is None or (isinstance(r["traffic"], (int, float)) and "profiles/" in r["traffic_source"])
+    assert r["bound"] == "fp64_valu" and r["kernel"].startswith("k_blind_rotate") and r["avg_launch_ms"] > 0
+    assert 0 < r["frac"] == r["algorithmic_frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-12
+    assert 0 < r["key_stream_vs_hbm_peak"] and "hbm_algorithmic_frac" not in r
+    assert r["launches"][0]["kernel"] == r["kernel"] and r["launches"][0]["launches_per_step"] == 1
+    # executed-instruction figures come from an offline PMC record and only if it was taken on these very kernel sources
+    assert (r["valu_frac"] is None and ("stale" in r["pmc"] or "no record" in r["pmc"] or "record is for" in r["pmc"])) or \
+        (0 < r["valu_frac"] < 1 and "profiles/" in r["pmc"])
+    assert "test-grade" in d["config"]["params"]["randomness"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["bit_exact_vs_gpu"] and c["cores"] >= 1 and c["cpu_model"] and c["one_thread"]["value"] > 0
     p = d["config"]["params"]

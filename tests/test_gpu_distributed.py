@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name,T", [("adder8__search_p7", 5), ("adder8__basic_p2", 3), ("edge_outputs", 4)])
+@pytest.mark.parametrize("name,T", [("adder8__search_p7", 5), ("adder8__basic_p2", 3), ("edge_outputs", 4),
+                                    ("full_adder__search_p7", 1)])        # T = 1: levels narrower than the world, empty slices
 def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")

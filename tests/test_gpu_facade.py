@@ -207,10 +207,16 @@ def test_eval_draws_fresh_randomness_every_call():
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     cfg = ExecConfig(reduced_noise=True)
     assert_outputs_equal(env.eval(ins, config=cfg), expect)
-    first = cfg._next_nonce
-    assert first == 4 * len(rec["program_inputs"]) and cfg.seed is not None
+    (ctx,) = cfg._contexts.values()
+    first = ctx.stat("next_nonce")
+    assert first == (1 << 55) + 4 * len(rec["program_inputs"]) and isinstance(cfg.seed, bytes)
     assert_outputs_equal(env.eval(ins, config=cfg), expect)
-    assert cfg._next_nonce == 2 * first
+    assert ctx.stat("next_nonce") == first + 4 * len(rec["program_inputs"])
+    assert cfg.last_choice["margin_sigmas"] > 0 and 0 <= cfg.last_choice["p_error_per_sample"] < 1
+    # two default encryptions of the same message share nothing; explicit nonces reproduce
+    m = np.arange(4)
+    assert not np.array_equal(ctx.encrypt(m), ctx.encrypt(m))
+    assert np.array_equal(ctx.encrypt(m, nonce0=9), ctx.encrypt(m, nonce0=9))
 
 
 def test_empty_inputs_give_empty_outputs(cfg15):

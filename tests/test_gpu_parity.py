@@ -409,10 +409,10 @@ def test_n4096_gadget_shapes_bit_exact(nat, toy_params, l, beta, t, gamma):
     (77, 8, 2, 9, 5, 3, 1),         # fewer columns than one tile is wide
 ])
 def test_matrix_core_key_switch_equals_the_integer_kernels(nat, n, log_n, l, beta, t, gamma, group):
-    """Batches above 64 key-switch as an int8 GEMM on the matrix cores (k_ks_gemm: balanced digits x balanced base-256 limbs of
-    the key, int32 sums, recombined mod q); smaller ones on the integer kernels, which the oracle tests pin word for word.
-    Same ciphertexts, so the same outputs: a batch of 203 (ragged against every tile size) against the same ciphertexts
-    in slices of 29."""
+    """The key switch runs as an int8 GEMM on the matrix cores (k_ks_gemm: balanced digits x balanced base-256 limbs of the
+    key, int32 sums, recombined mod q) for every batch size; the integer kernels it replaced stay as the fallback and are
+    reached here through the launcher knob.  Same ciphertexts, so the same outputs: a batch of 203 (ragged against every
+    tile size) on the GEMM against the same ciphertexts in slices of 29 on the integer kernels."""
     from tfhe_fbs_map_amd import Params
     prm = Params(n=n, log_n_poly=log_n, l_bsk=l, beta_bsk=beta, t_ksk=t, gamma_ksk=gamma, p_msg=7, sigma_lwe=1 << 10,
                  sigma_glwe=1 << 4, bsk_group=group)
@@ -429,11 +429,15 @@ def test_matrix_core_key_switch_equals_the_integer_kernels(nat, n, log_n, l, bet
     whole = ctx.bootstrap_batch(tv, cts, ids)
     ctx.profile(True)
     ctx.profile_read()
+    ctx.tune(ks_mfma=0)
     parts = np.concatenate([ctx.bootstrap_batch(tv, cts[i:i + 29], ids[i:i + 29]) for i in range(0, count, 29)])
     assert "k_keyswitch" in ctx.profile_read()["keyswitch"]["kernel"]
+    ctx.tune(ks_mfma=1)
     ctx.bootstrap_batch(tv, cts, ids)
     assert "k_ks_gemm" in ctx.profile_read()["keyswitch"]["kernel"]
     assert np.array_equal(whole, parts)
+    one = ctx.bootstrap_batch(tv, cts[:1], ids[:1])                               # the GEMM on a single row
+    assert "k_ks_gemm" in ctx.profile_read()["keyswitch"]["kernel"] and np.array_equal(one, whole[:1])
 
 
 def test_matrix_core_key_switch_over_several_passes_and_changing_batch_sizes(nat, toy_params):
@@ -444,8 +448,154 @@ def test_matrix_core_key_switch_over_several_passes_and_changing_batch_sizes(nat
     ctx = nat.Context(prm, seed=4)
     tv = ctx.tvset([[0, 1, 1, 0, 1, 0, 0]])
     rng = np.random.default_rng(0)
-    for count in (8192 + 77, 65, 700, 129, 8192):
+    for count in (8192 + 77, 65, 700, 129, 8192, 3):
         cts = ctx.encrypt(rng.integers(0, 7, count), nonce0=count)
+        ctx.tune(ks_mfma=1)
         whole = ctx.bootstrap_batch(tv, cts)
+        ctx.tune(ks_mfma=0)
         parts = np.concatenate([ctx.bootstrap_batch(tv, cts[i:i + 64]) for i in range(0, count, 64)])
         assert np.array_equal(whole, parts), count
+
+
+def test_ciphertext_kats_on_the_gpu(nat):
+    """The kernels against the committed digests (tests/golden/_ciphertext_kats.json, written from the oracle): same keys, same
+    encryptions, same bootstrap outputs, at P1024, at three 128-bit sets and for a fused program."""
+    import hashlib
+    import json
+    import os
+    from tfhe_fbs_map_amd import Params, parse_fbs
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "_ciphertext_kats.json")) as f:
+        kats = json.load(f)["kats"]
+
+    def digest(a):
+        return hashlib.sha256(np.ascontiguousarray(a, dtype=np.uint64).tobytes()).hexdigest()
+
+    for name, kat in kats.items():
+        prm = Params(**kat["params"])
+        ctx = nat.Context(prm, seed=kat["seed"])
+        if kat["kind"] == "batch":
+            keys = ctx.export_keys()
+            assert digest(keys["sk_lwe"]) == kat["sha256"]["sk_lwe"] and digest(keys["sk_glwe"]) == kat["sha256"]["sk_glwe"], name
+            assert digest(keys["bsk"][:2 * prm.N]) == kat["sha256"]["bsk_first_row"], name
+            assert digest(keys["ksk"][:prm.n + 1]) == kat["sha256"]["ksk_first_row"], name
+            cts = ctx.encrypt(np.array(kat["msgs"]), nonce0=kat["nonce0"])
+            for i in kat["trivial"]:
+                cts[i, :-1] = 0
+            assert digest(cts) == kat["sha256"]["inputs"], name
+            out = ctx.bootstrap_batch(ctx.tvset(kat["tables"]), cts, np.array(kat["table_ids"], np.uint32))
+            assert digest(out) == kat["sha256"]["outputs"], name
+            assert [int(v) for v in ctx.decrypt(out)] == kat["decrypts_to"], name
+        else:
+            rec = load_fixture(kat["fixture"])
+            env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+            low = env.lower()
+            prog = nat.Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                               low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=True)
+            T = kat["samples"]
+            ins, _ = subsample(rec, T)
+            cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=kat["nonce0"])
+            assert digest(cts) == kat["sha256"]["inputs"], name
+            got = prog.eval(cts, T)
+            ops, outs = lut_oracle.read_fbs(rec["fbs"])
+            keep = [k for k, (_, src) in enumerate(outs) if src not in ("0", "1")]
+            assert low["out_names"] == [o_name for o_name, _ in outs]
+            assert digest(got[keep]) == kat["sha256"]["outputs"], name
+        ctx.close()
+
+
+def test_headline_shape_at_full_size_against_the_oracle(p1024_pair):
+    """BASELINE config 2 as the bench runs it -- P1024 at n = 630, 1024 ciphertexts through fbs_bootstrap_batch_dev, the
+    whole-CU kernel k_blind_rotate<10,6,3,4> -- word for word against the oracle on ciphertexts chosen to sit in every
+    sub-slot (bootstrap 0 .. 3 of a workgroup = a different pair of waves on every SIMD) of the first, a middle and the last
+    workgroup, including trivial ciphertexts (every rotation amount zero: the bootstrap only keeps its workgroup's barriers
+    company) next to ordinary ones.  Then a launch the launcher CUTS: 1024 + 100 -- a whole round, and the leftovers on the
+    one-bootstrap-per-CU kernel -- checked on both sides of the cut."""
+    import torch
+    ctx, o = p1024_pair
+    rng = np.random.default_rng(7)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
+    tv = ctx.tvset(tables)
+    for B, pick, want in ((1024, [0, 1, 2, 3, 4, 5, 6, 7, 510, 513, 1020, 1021, 1022, 1023, 301, 778],
+                           ["k_blind_rotate<10,6,3,4>"]),
+                          (1124, [0, 3, 1021, 1023, 1024, 1025, 1100, 1123],
+                           ["k_blind_rotate<10,6,3,4>", "k_blind_rotate_cu<10,3,2>"])):
+        msgs = rng.integers(0, 15, B)
+        ids = (np.arange(B) % 16).astype(np.uint32)
+        cts = ctx.encrypt(msgs, nonce0=100)
+        for i in (1, 6, 1022, B - 1):
+            cts[i, :-1] = 0                                          # trivial: mask zero, so every modulus-switched mask word is zero
+        d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+        d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+        d_out = torch.empty_like(d_in)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, d_out.data_ptr())
+        ctx.sync()
+        launched = ctx.profile_kernels()
+        ctx.profile(False)
+        assert [k for k in launched if "blind_rotate" in k] == want or sorted(k for k in launched if "blind_rotate" in k) == sorted(want)
+        got = d_out.cpu().numpy().view(np.uint64)
+        ref, _ = o.bootstrap_batch(cts[pick], tables, ids[pick])
+        assert np.array_equal(got[pick], ref), B
+        keep = np.ones(B, bool)
+        keep[[1, 6, 1022, B - 1]] = False
+        assert np.array_equal(ctx.decrypt(got)[keep], np.array([tables[i][m] for i, m in zip(ids, msgs)])[keep])
+
+
+def test_imported_keys_give_the_oracles_ciphertexts(nat, toy_params):
+    """fbs_import_keys: keys made elsewhere -- here by the oracle under ANOTHER seed -- instead of fbs_keygen.  The context then
+    bootstraps exactly as the oracle does with those keys, and refuses keys that are not canonical."""
+    prm = toy_params.replace(n=16)
+    o = orc.Oracle(prm, seed=77)
+    ctx = nat.Context(prm, seed=5, keygen=False)
+    with pytest.raises(nat.FbsError):
+        ctx.encrypt(np.arange(3), nonce0=0)                           # no keys yet
+    keys = o.keys()
+    bad = keys["ksk"].copy()
+    bad[3] = orc.Q
+    with pytest.raises(nat.FbsError, match="canonical"):
+        ctx.import_keys(keys["sk_lwe"], keys["sk_glwe"], keys["bsk"], bad)
+    ctx.import_keys(**keys)
+    mine = ctx.export_keys()
+    assert all(np.array_equal(mine[k], keys[k]) for k in keys)
+    msgs = np.concatenate([np.arange(len(t)) for t in MODES])
+    ids = np.concatenate([np.full(len(t), i) for i, t in enumerate(MODES)]).astype(np.uint32)
+    cts = o.encrypt(msgs, nonce0=4)                                   # the oracle's encryptions under its keys
+    got = ctx.bootstrap_batch(ctx.tvset(MODES), cts, ids)
+    ref, _ = o.bootstrap_batch(cts, MODES, ids)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(ctx.decrypt(got), np.concatenate([np.array(t) for t in MODES]))
+    # a context keyed with 32 bytes: other keys than the 64-bit form, and other keys for another parameter set under the same bytes
+    raw = bytes(range(32))
+    a, b = nat.Context(prm, seed=raw), nat.Context(prm.replace(n=20), seed=raw)
+    ka, kb = a.export_keys(), b.export_keys()
+    assert not np.array_equal(ka["sk_lwe"], kb["sk_lwe"][:16]) and not np.array_equal(ka["sk_glwe"], kb["sk_glwe"])
+    assert np.array_equal(nat.Context(prm, seed=raw).export_keys()["sk_glwe"], ka["sk_glwe"])
+    m = np.arange(10) % 7
+    assert np.array_equal(a.decrypt(a.bootstrap_batch(a.tvset([MODES[0]]), a.encrypt(m))), [MODES[0][v] for v in m])
+
+
+def test_reserved_scratch_never_grows(nat, toy_params):
+    """fbs_ctx_reserve: after sizing the scratch once, *_dev calls on two streams are kernel launches and nothing else -- the
+    counter of (blocking) scratch growths stays where it was; without the reservation the first larger call grows it."""
+    import torch
+    ctx = nat.Context(toy_params, seed=3)
+    tv = ctx.tvset([MODES[0]])
+    cts = ctx.encrypt(np.arange(600) % 7, nonce0=0)
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.reserve(max_keyswitches=600)
+    before = ctx.stat("scratch_growths")
+    assert before > 0 and ctx.stat("ms_capacity") >= 600
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for count, s in ((40, s1), (600, s2), (129, s1), (600, s1)):
+        ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), 0, count, d_out.data_ptr(), s.cuda_stream)
+    assert ctx.stat("scratch_growths") == before
+    torch.cuda.synchronize()
+    assert np.array_equal(ctx.decrypt(d_out.cpu().numpy().view(np.uint64)), [MODES[0][v] for v in np.arange(600) % 7])
+    other = nat.Context(toy_params, seed=3)
+    other.bootstrap_batch(other.tvset([MODES[0]]), cts[:8])
+    g0 = other.stat("scratch_growths")
+    other.bootstrap_batch(other.tvset([MODES[0]]), cts[:300])
+    assert other.stat("scratch_growths") > g0

@@ -233,3 +233,30 @@ def test_modulus_switch_is_mean_compensated():
     assert abs(errs.mean()) < 0.5
     assert 0.8 * (1 + n / 4) / 12 < var < 1.2 * (1 + n / 4) / 12, var
     assert var < 0.65 * (1 + n / 2) / 12
+
+
+def _kat_module():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_ciphertext_kats.py")
+    spec = importlib.util.spec_from_file_location("make_ciphertext_kats", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_ciphertext_kats():
+    """The oracle against the committed digests of its own output (tests/golden/_ciphertext_kats.json): key derivation,
+    encryption, key switch + modulus switch and bootstrap outputs for fixed seeds at P1024, three 128-bit sets (one and two
+    key bits per step) and a fused program.  GPU == oracle says the kernels follow the oracle; this says the oracle has not
+    moved.  A deliberate change of conventions regenerates the file in the same commit (see the generator's docstring)."""
+    import json
+    mod = _kat_module()
+    with open(mod.OUT) as f:
+        want = json.load(f)
+    assert want["modulus"] == orc.Q
+    assert set(want["kats"]) == set(mod.SETS) | {"fused_adder8"}
+    for name, prm in mod.SETS.items():
+        got = mod.batch_case(name, prm)
+        assert got == want["kats"][name], name
+    assert mod.fused_case() == want["kats"]["fused_adder8"]

@@ -18,6 +18,10 @@ LIB_PATH = os.environ.get("FBS_LIB") or os.path.join(_HERE, "libfbsexec.so")   #
 from .security import MODULUS, MODULUS_BITS, sigma_min      # noqa: E402,F401
 
 
+RANDOMNESS_GRADE = ("test-grade: ChaCha20 streams keyed by the context seed; noise = integer Irwin-Hall(12) stand-in for a discrete "
+                    "Gaussian, bounded at 6 sigma.  Bring keys made with a production sampler through Context.import_keys")
+
+
 class FbsError(RuntimeError):
     def __init__(self, code, text):
         super().__init__(f"libfbsexec error {code}: {text}")
@@ -129,13 +133,19 @@ def _load():
     sig = {
         "fbs_poly_size_check": (i32, [u32]),
         "fbs_ctx_create": (i32, [C.POINTER(_Params), u64, i32, C.POINTER(vp)]),
+        "fbs_ctx_create_seeded": (i32, [C.POINTER(_Params), vp, i32, C.POINTER(vp)]),
         "fbs_ctx_destroy": (None, [vp]),
+        "fbs_ctx_reserve": (i32, [vp, sz, sz, sz]),
+        "fbs_ctx_tune": (i32, [vp, C.c_char_p, C.c_int64]),
+        "fbs_ctx_stat": (i32, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
         "fbs_last_error": (C.c_char_p, [vp]),
         "fbs_device_info": (C.c_char_p, [vp]),
         "fbs_keygen": (i32, [vp]),
         "fbs_key_sizes": (i32, [vp, C.POINTER(sz * 4)]),
         "fbs_export_keys": (i32, [vp, vp, vp, vp, vp]),
+        "fbs_import_keys": (i32, [vp, vp, vp, vp, vp]),
         "fbs_encrypt": (i32, [vp, vp, sz, u64, vp]),
+        "fbs_encrypt_fresh": (i32, [vp, vp, sz, vp, C.POINTER(u64)]),
         "fbs_decrypt": (i32, [vp, vp, sz, vp]),
         "fbs_tvset_create": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
         "fbs_tvset_destroy": (None, [vp]),
@@ -159,6 +169,8 @@ def _load():
         "fbs_profile_enable": (i32, [vp, i32]),
         "fbs_profile_read": (i32, [vp, C.POINTER(C.c_double * 3), C.POINTER(u64 * 3), i32]),
         "fbs_profile_kernel": (C.c_char_p, [vp, i32]),
+        "fbs_kernel_catalog": (C.c_char_p, []),
+        "fbs_profile_kernels": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "fbs_sync": (i32, [vp, vp]),
         "fbs_debug_polymul": (i32, [vp, vp, vp, vp]),
         "fbs_searcher_create": (i32, [i32, C.POINTER(vp)]),
@@ -175,14 +187,15 @@ def _load():
 
 
 EXPORTED_SYMBOLS = (
-    "fbs_poly_size_check", "fbs_ctx_create", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
+    "fbs_poly_size_check", "fbs_ctx_create", "fbs_ctx_create_seeded", "fbs_ctx_reserve", "fbs_ctx_tune", "fbs_ctx_stat",
+    "fbs_import_keys", "fbs_encrypt_fresh", "fbs_ctx_destroy", "fbs_last_error", "fbs_device_info", "fbs_keygen",
     "fbs_key_sizes", "fbs_export_keys", "fbs_encrypt", "fbs_decrypt", "fbs_tvset_create",
     "fbs_tvset_destroy", "fbs_bootstrap_batch", "fbs_bootstrap_batch_dev", "fbs_lincomb_dev",
     "fbs_bootstrap_wires_dev", "fbs_program_load", "fbs_program_load_ex", "fbs_table_fusion_norms", "fbs_program_destroy",
     "fbs_program_info",
     "fbs_searcher_create", "fbs_searcher_destroy", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms",
     "fbs_search_lincomb_coefs", "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
-    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
+    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_kernel_catalog", "fbs_profile_kernels", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
 )
 
 lib = _load()
@@ -194,6 +207,11 @@ def _ptr(a):
 
 def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def kernel_catalog():
+    """Names of every kernel instantiation the launchers can pick (fbs_kernel_catalog)."""
+    return [n for n in lib.fbs_kernel_catalog().decode().split("\n") if n]
 
 
 class TvSet:
@@ -285,16 +303,26 @@ class Program:
 class Context:
     """One GPU, one parameter set, one key set."""
 
-    def __init__(self, params: Params, seed: int | None = None, device: int = 0, keygen: bool = True):
-        """seed: all key material and encryption randomness derive from it; None draws one from os.urandom
-        (tests and benchmarks pass a constant so that the CPU oracle can be keyed identically)."""
-        if seed is None:
-            seed = int.from_bytes(os.urandom(8), "little")
+    def __init__(self, params: Params, seed: int | bytes | None = None, device: int = 0, keygen: bool = True):
+        """seed: what all key material and encryption randomness derive from.
+        * an int: the REPRODUCIBLE form (fbs_ctx_create, 64 bits) -- tests and benchmarks pass a constant so that the CPU
+          oracle can be keyed identically.  Not a way to make production keys.
+        * None or 32 bytes: fbs_ctx_create_seeded -- 256 bits (None: from os.urandom) with the parameter set mixed into the
+          derivation.
+        Either way the noise sampler is a test-grade stand-in for a discrete Gaussian (`RANDOMNESS_GRADE`); a deployment
+        that needs more brings its own keys with `import_keys`.  keygen=False leaves the context without keys (for
+        `import_keys`)."""
         self.params = params
         self.seed = seed
         self._h = C.c_void_p()
         cp = params.to_c()
-        rc = lib.fbs_ctx_create(C.byref(cp), seed, device, C.byref(self._h))
+        if isinstance(seed, int):
+            rc = lib.fbs_ctx_create(C.byref(cp), seed, device, C.byref(self._h))
+        else:
+            raw = os.urandom(32) if seed is None else bytes(seed)
+            if len(raw) != 32:
+                raise ValueError("a byte seed has 32 bytes")
+            rc = lib.fbs_ctx_create_seeded(C.byref(cp), raw, device, C.byref(self._h))
         if rc != 0:
             self._h = None
             raise FbsError(rc, lib.fbs_last_error(None).decode())
@@ -327,10 +355,39 @@ class Context:
         self._check(lib.fbs_export_keys(self._h, *[_ptr(a) for a in arrs]))
         return dict(sk_lwe=arrs[0], sk_glwe=arrs[1], bsk=arrs[2], ksk=arrs[3])
 
-    def encrypt(self, msgs, nonce0=0):
+    def import_keys(self, sk_lwe, sk_glwe, bsk, ksk):
+        """Keys made elsewhere (layout of `export_keys`) instead of `keygen`: a caller's own CSPRNG and sampler, or a checker's."""
+        arrs = [_c(a, np.uint64).ravel() for a in (sk_lwe, sk_glwe, bsk, ksk)]
+        sizes = (C.c_size_t * 4)()
+        self._check(lib.fbs_key_sizes(self._h, C.byref(sizes)))
+        for a, want, name in zip(arrs, sizes, ("sk_lwe", "sk_glwe", "bsk", "ksk")):
+            if a.size != want:
+                raise ValueError(f"{name} has {a.size} words, the parameter set needs {want}")
+        self._check(lib.fbs_import_keys(self._h, *[_ptr(a) for a in arrs]))
+
+    def reserve(self, max_keyswitches=0, max_shared_rows=0, wire_words=0):
+        """Size the scratch up front so that no later `*_dev` call has to grow it (growing blocks): include/fbs_exec.h."""
+        self._check(lib.fbs_ctx_reserve(self._h, int(max_keyswitches), int(max_shared_rows), int(wire_words)))
+
+    def tune(self, **knobs):
+        """Launcher knobs (`fbs_ctx_tune`): which kernel shape a launch takes; results never depend on them."""
+        for k, v in knobs.items():
+            self._check(lib.fbs_ctx_tune(self._h, k.encode(), int(v)))
+
+    def stat(self, name):
+        v = C.c_int64()
+        self._check(lib.fbs_ctx_stat(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def encrypt(self, msgs, nonce0=None):
+        """nonce0=None: streams nobody has used (the context counts them: no two calls share mask or noise); an int: ciphertext
+        i takes stream nonce0 + i -- reproducible, for tests and checkers."""
         msgs = _c(msgs, np.int64)
         cts = np.empty(msgs.shape + (self.params.ct_words,), np.uint64)
-        self._check(lib.fbs_encrypt(self._h, _ptr(msgs), msgs.size, nonce0, _ptr(cts)))
+        if nonce0 is None:
+            self._check(lib.fbs_encrypt_fresh(self._h, _ptr(msgs), msgs.size, _ptr(cts), None))
+        else:
+            self._check(lib.fbs_encrypt(self._h, _ptr(msgs), msgs.size, nonce0, _ptr(cts)))
         return cts
 
     def decrypt(self, cts):
@@ -376,6 +433,19 @@ class Context:
         names = ("keyswitch", "blind_rotate", "lincomb")
         return {n: dict(ms=ms[i], launches=int(cnt[i]), kernel=lib.fbs_profile_kernel(self._h, i).decode())
                 for i, n in enumerate(names)}
+
+    def profile_kernels(self):
+        """{kernel instantiation: dict(kind, launches, ms)} since the last reset -- a launch cut into a whole-round part and a
+        remainder shows as two entries."""
+        need = C.c_size_t()
+        self._check(lib.fbs_profile_kernels(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value)
+        self._check(lib.fbs_profile_kernels(self._h, buf, need.value, None))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            kind, name, launches, ms = line.split("\t")
+            out[name] = dict(kind=("keyswitch", "blind_rotate", "lincomb")[int(kind)], launches=int(launches), ms=float(ms))
+        return out
 
     def sync(self, stream=0):
         self._check(lib.fbs_sync(self._h, stream or None))

@@ -642,9 +642,8 @@ int dev_upload_keys(fbs_ctx *ctx) {
 // How many bootstraps of a launch of `count` go to whole-CU workgroups: all of them when the last round is (nearly) full,
 // else the whole rounds only -- the rest follows as a launch of its own in the shape that suits its size (a partly
 // filled round is faster as small workgroups: 768 bootstraps 8.2 ms against 9.3).
-static size_t whole_cu_share(size_t count, size_t per_round) {
-    static const bool off = getenv("FBS_BR_SMALL_WORKGROUPS") != nullptr;   // (A/B switch)
-    if (off) return 0;
+static size_t whole_cu_share(const fbs_ctx *ctx, size_t count, size_t per_round) {
+    if (!ctx->tune.br_whole_cu) return 0;   // (A/B switch)
     const size_t r = count % per_round;
     return (r == 0 || 8 * r >= 7 * per_round) ? count : count - r;
 }
@@ -711,14 +710,17 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     prof_begin(ctx, 1, stream, &e0, &e1);
     {
         // launches that leave most of the chip empty: one bootstrap on the eight waves of a CU (fbs_blind_rotate_cu.hip)
-        static const int cu_max = getenv("FBS_BR_CU_MAX_PER_CU") ? atoi(getenv("FBS_BR_CU_MAX_PER_CU")) : 1;   // (tuning)
-        if (ctx->d_bsk_hat_small && count <= (size_t)ctx->cu_count * (size_t)cu_max && launch_blind_rotate_cu(ctx, a, stream, &ctx->prof.kernel[1])) {
+        // Up to TWO bootstraps per CU: the second round of workgroups follows the first CU by CU (512 bootstraps: 5.9 ms against
+        // 6.5 ms for two bootstraps side by side in the two-waves-per-bootstrap kernel; 384: 6.0 against 6.5).  Beyond that
+        // the small workgroups of k_blind_rotate win (768: 8.3 ms against three rounds of 2.95).
+        if (ctx->d_bsk_hat_small && count <= (size_t)ctx->cu_count * (size_t)ctx->tune.br_cu_max_per_cu &&
+            launch_blind_rotate_cu(ctx, a, stream, &ctx->prof.kernel[1])) {
             prof_end(ctx, 1, stream, e0, e1);
             FBS_HIP(ctx, hipGetLastError());
             return FBS_OK;
         }
     }
-    const size_t whole = (p.log_n_poly == 10 && dig == 3) ? whole_cu_share(count, 4 * (size_t)ctx->cu_count) : 0;
+    const size_t whole = (p.log_n_poly == 10 && dig == 3) ? whole_cu_share(ctx, count, 4 * (size_t)ctx->cu_count) : 0;
     if (whole) {
         // the benchmark shape: four bootstraps = the eight waves of a CU in one workgroup
         a.count = whole;
@@ -785,6 +787,29 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     prof_end(ctx, 1, stream, e0, e1);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;
+}
+
+// Every blind-rotation instantiation dev_blind_rotate can pick, by the rules of the dispatch above (fbs_kernel_catalog;
+// tests/test_gpu_dispatch.py drives each one and checks it against the oracle)
+void blind_rotate_catalog(std::vector<std::string> *out) {
+    auto name = [](int L, int ll, int dig, int fpw) {
+        return "k_blind_rotate<" + std::to_string(L) + "," + std::to_string(ll) + "," + std::to_string(dig) + "," + std::to_string(fpw) + ">";
+    };
+    for (int L : {8, 9, 10, 11, 12}) {
+        const int ll = lanes_log2_for(L), small = lanes_log2_for_small_launch(L);
+        for (int dig = 0; dig < 8; dig++) {
+            out->push_back(name(L, ll, dig, 1));
+            if (ll == 6) out->push_back(name(L, ll, dig, 2));
+            if (small != ll) out->push_back(name(L, small, dig, 1));
+        }
+    }
+    out->push_back("k_blind_rotate<10,6,3,4>");
+    out->push_back("k_blind_rotate<10,6,6,1,false>");
+    out->push_back("k_blind_rotate<10,6,7,1,false>");
+    for (int L : {10, 11, 12})
+        for (int dig : {0, 3, 4})
+            out->push_back("k_blind_rotate_pairs<" + std::to_string(L) + "," + std::to_string(lanes_log2_for(L)) + "," + std::to_string(dig) + ">");
+    blind_rotate_cu_catalog(out);
 }
 
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream) {

@@ -242,8 +242,7 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
     if (p.log_n_poly != 10 || ctx->group != 1 || !ctx->d_bsk_hat_small || p.l_bsk > 4) return false;
-    static const bool off = getenv("FBS_BR_NO_CU_KERNEL") != nullptr;   // (A/B switch: the generic kernel on the four-wave transform)
-    if (off) return false;
+    if (!ctx->tune.br_cu_kernel) return false;   // (A/B switch: the generic kernel on the four-wave transform)
     const int first = p.beta_bsk <= 7 ? 2 : p.beta_bsk <= 9 ? 1 : 0;
     BrArgs b = a;
     b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
@@ -257,9 +256,15 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
     CU_CASE(1, 0) CU_CASE(1, 1) CU_CASE(1, 2)
     CU_CASE(2, 0) CU_CASE(2, 1) CU_CASE(2, 2)
     CU_CASE(3, 0) CU_CASE(3, 1) CU_CASE(3, 2)
-    CU_CASE(4, 0) CU_CASE(4, 1) CU_CASE(4, 2)
+    CU_CASE(4, 2)   // (l * beta <= 30: four levels have at most 7 bits each)
 #undef CU_CASE
     return false;
+}
+
+void blind_rotate_cu_catalog(std::vector<std::string> *out) {
+    for (int nl = 1; nl <= 4; nl++)
+        for (int first = nl == 4 ? 2 : 0; first < 3; first++)
+            out->push_back("k_blind_rotate_cu<10," + std::to_string(nl) + "," + std::to_string(first) + ">");
 }
 
 }  // namespace fbs

@@ -2,6 +2,7 @@
 // program executor that stands behind `LutExecEnv.eval` (reference fbs_mapper/fbs_exec_env.py:208-229).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -81,8 +82,12 @@ static uint64_t coef_bits(int64_t c) {
 
 static hipStream_t pick(fbs_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// Scratch is grown on demand, and growing it BLOCKS (the old buffers may still be read by queued kernels): a host that wants
+// its *_dev calls to be nothing but kernel launches sizes everything up front with fbs_ctx_reserve.
 static int ensure_ms(fbs_ctx *ctx, size_t count) {
+    if (int rc = dev_keyswitch_reserve(ctx, count)) return rc;   // (the int8-GEMM key switch's digit and limb-sum scratch)
     if (count <= ctx->ms_capacity) return FBS_OK;
+    ctx->scratch_growths++;
     if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // kernels may still read the old buffer
     for (void *p : {(void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body})
         if (p) (void)hipFree(p);
@@ -101,12 +106,25 @@ static int ensure_ms(fbs_ctx *ctx, size_t count) {
 
 static int ensure_acc(fbs_ctx *ctx, size_t rows) {
     if (rows <= ctx->acc_capacity) return FBS_OK;
+    ctx->scratch_growths++;
     if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
     if (ctx->d_acc) (void)hipFree(ctx->d_acc);
     ctx->d_acc = nullptr;
     ctx->acc_capacity = 0;
     FBS_HIP(ctx, hipMalloc(&ctx->d_acc, rows * 2 * (size_t)ctx->N * 8));
     ctx->acc_capacity = rows;
+    return FBS_OK;
+}
+
+static int ensure_wires(fbs_ctx *ctx, size_t words) {
+    if (words <= ctx->wires_capacity) return FBS_OK;
+    ctx->scratch_growths++;
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
+    if (ctx->d_wires) (void)hipFree(ctx->d_wires);
+    ctx->d_wires = nullptr;
+    ctx->wires_capacity = 0;
+    FBS_HIP(ctx, hipMalloc(&ctx->d_wires, words * 8));
+    ctx->wires_capacity = words;
     return FBS_OK;
 }
 
@@ -121,6 +139,15 @@ static int scratch_done(fbs_ctx *ctx, hipStream_t s) {
     ctx->scratch_stream = s;
     ctx->scratch_used = true;
     return FBS_OK;
+}
+
+// A call that fails between scratch_wait and scratch_done may have left the "zero between launches" scratch (rounding-error
+// sums, limb sums of the GEMM key switch) half used: put it back, so that the next call on the context starts clean.
+static int scratch_fail(fbs_ctx *ctx, hipStream_t s, int rc) {
+    if (ctx->d_ms_eps && ctx->ms_capacity) (void)hipMemsetAsync(ctx->d_ms_eps, 0, ctx->ms_capacity * 8, s);
+    (void)dev_keyswitch_rezero(ctx, s);
+    (void)scratch_done(ctx, s);
+    return rc;
 }
 
 // the plain batch: gate g = ciphertext g, one sample each
@@ -157,13 +184,28 @@ int fbs_poly_size_check(uint32_t poly_size) {
     return FBS_OK;
 }
 
-int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) {
+static int64_t env_knob(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    return e && *e ? atoll(e) : dflt;
+}
+
+static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *seed32, int device, fbs_ctx **out) {
     if (!params || !out) return set_error(nullptr, FBS_E_INVALID, "null argument");
     *out = nullptr;
     std::unique_ptr<fbs_ctx> ctx(new fbs_ctx);
     ctx->p = *params;
     ctx->seed = seed;
+    ctx->rkey = seed32 ? rand_key_derive(seed32, *params) : rand_key_from_seed64(seed);
     ctx->device = device;
+    // A/B switches of the launchers, settable per context with fbs_ctx_tune; the environment gives the defaults of a process
+    ctx->tune.ks_gemm_min = env_knob("FBS_KS_GEMM_MIN", ctx->tune.ks_gemm_min);
+    ctx->tune.ks_mfma = env_knob("FBS_KS_NO_MFMA", 0) ? 0 : 1;
+    ctx->tune.ks_fp = env_knob("FBS_KS_INTEGER", 0) ? 0 : 1;
+    ctx->tune.ks_cols_major = env_knob("FBS_KS_TILES_MAJOR", 0) ? 0 : 1;
+    ctx->tune.ks_split = env_knob("FBS_KS_SPLIT", 0);
+    ctx->tune.br_whole_cu = getenv("FBS_BR_SMALL_WORKGROUPS") ? 0 : 1;
+    ctx->tune.br_cu_kernel = getenv("FBS_BR_NO_CU_KERNEL") ? 0 : 1;
+    ctx->tune.br_cu_max_per_cu = env_knob("FBS_BR_CU_MAX_PER_CU", ctx->tune.br_cu_max_per_cu);
     const fbs_params &p = ctx->p;
     if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
         p.t_ksk > 64)
@@ -213,6 +255,51 @@ int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx 
     return FBS_OK;
 }
 
+int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) {
+    return ctx_create(params, seed, nullptr, device, out);
+}
+
+int fbs_ctx_create_seeded(const fbs_params *params, const uint8_t seed[32], int device, fbs_ctx **out) {
+    if (!seed) return set_error(nullptr, FBS_E_INVALID, "null seed");
+    return ctx_create(params, 0, seed, device, out);
+}
+
+int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) {
+    if (!ctx || !knob) return FBS_E_INVALID;
+    const std::string k(knob);
+    Tune &t = ctx->tune;
+    int64_t *slot = k == "ks_gemm_min" ? &t.ks_gemm_min : k == "ks_mfma" ? &t.ks_mfma : k == "ks_fp" ? &t.ks_fp :
+                    k == "ks_cols_major" ? &t.ks_cols_major : k == "ks_split" ? &t.ks_split : k == "br_whole_cu" ? &t.br_whole_cu :
+                    k == "br_cu_kernel" ? &t.br_cu_kernel : k == "br_cu_max_per_cu" ? &t.br_cu_max_per_cu : nullptr;
+    if (!slot) return set_error(ctx, FBS_E_INVALID, "unknown knob '" + k + "'");
+    if (value < 0) return set_error(ctx, FBS_E_INVALID, "knob values are non-negative");
+    *slot = value;
+    return FBS_OK;
+}
+
+int fbs_ctx_stat(const fbs_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return FBS_E_INVALID;
+    const std::string k(name);
+    if (k == "scratch_growths") *value = ctx->scratch_growths;
+    else if (k == "ms_capacity") *value = (int64_t)ctx->ms_capacity;
+    else if (k == "acc_capacity") *value = (int64_t)ctx->acc_capacity;
+    else if (k == "wires_capacity") *value = (int64_t)ctx->wires_capacity;
+    else if (k == "next_nonce") *value = (int64_t)ctx->next_nonce;
+    else if (k == "cu_count") *value = ctx->cu_count;
+    else return set_error(ctx, FBS_E_INVALID, "unknown statistic '" + k + "'");
+    return FBS_OK;
+}
+
+int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows, size_t wire_words) {
+    if (!ctx) return FBS_E_INVALID;
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (max_keyswitches && (rc = ensure_ms(ctx, max_keyswitches)) != FBS_OK) return rc;
+    if (max_shared_rows && (rc = ensure_acc(ctx, max_shared_rows)) != FBS_OK) return rc;
+    if (wire_words && (rc = ensure_wires(ctx, wire_words)) != FBS_OK) return rc;
+    return FBS_OK;
+}
+
 void fbs_ctx_destroy(fbs_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -224,8 +311,8 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
     for (auto &v : ctx->prof.pending)
         for (auto &pr : v) {
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
+            (void)hipEventDestroy(pr.begin);
+            (void)hipEventDestroy(pr.end);
         }
     for (auto &pr : ctx->prof.pool) {
         (void)hipEventDestroy(pr.first);
@@ -268,9 +355,48 @@ int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uin
     return FBS_OK;
 }
 
+int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk, const uint64_t *ksk) {
+    if (!ctx) return FBS_E_INVALID;
+    if (!sk_lwe || !sk_glwe || !bsk || !ksk) return set_error(ctx, FBS_E_INVALID, "null argument");
+    FBS_HIP(ctx, hipSetDevice(ctx->device));
+    size_t sizes[4];
+    fbs_key_sizes(ctx, sizes);
+    for (size_t i = 0; i < sizes[0]; i++)
+        if (sk_lwe[i] > 1) return set_error(ctx, FBS_E_INVALID, "secret keys are binary");
+    for (size_t i = 0; i < sizes[1]; i++)
+        if (sk_glwe[i] > 1) return set_error(ctx, FBS_E_INVALID, "secret keys are binary");
+    for (size_t i = 0; i < sizes[2]; i++)
+        if (bsk[i] >= FQ) return set_error(ctx, FBS_E_INVALID, "bootstrapping-key word is not a canonical residue");
+    for (size_t i = 0; i < sizes[3]; i++)
+        if (ksk[i] >= FQ) return set_error(ctx, FBS_E_INVALID, "key-switching-key word is not a canonical residue");
+    if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // kernels may still read the old keys
+    ctx->sk_lwe.assign(sk_lwe, sk_lwe + sizes[0]);
+    ctx->sk_glwe.assign(sk_glwe, sk_glwe + sizes[1]);
+    ctx->bsk.assign(bsk, bsk + sizes[2]);
+    ctx->ksk.assign(ksk, ksk + sizes[3]);
+    ctx->have_keys = false;
+    int rc = dev_upload_keys(ctx);
+    if (rc != FBS_OK) return rc;
+    ctx->have_keys = true;
+    return FBS_OK;
+}
+
+int fbs_encrypt_fresh(fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t *cts, uint64_t *nonce0) {
+    if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
+    if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    if (ctx->next_nonce + count > (1ull << 56)) return set_error(ctx, FBS_E_STATE, "encryption streams of this context are used up");
+    const uint64_t first = ctx->next_nonce;
+    ctx->next_nonce += count;
+    if (nonce0) *nonce0 = first;
+    host_encrypt(ctx, msgs, count, first, cts);
+    return FBS_OK;
+}
+
 int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts) {
     if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
     if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
+    // streams [2^55, 2^56) belong to fbs_encrypt_fresh: an explicit nonce can never repeat one the context handed out itself
+    if (nonce0 >= (1ull << 55) || count > (1ull << 55) - nonce0) return set_error(ctx, FBS_E_INVALID, "nonce0 + count must stay below 2^55");
     host_encrypt(ctx, msgs, count, nonce0, cts);
     return FBS_OK;
 }
@@ -373,9 +499,9 @@ int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d
     hipStream_t s = pick(ctx, stream);
     if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
     rc = dev_keyswitch(ctx, gv, ctx->d_ms, s);
-    if (rc != FBS_OK) return rc;
+    if (rc != FBS_OK) return scratch_fail(ctx, s, rc);
     rc = dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
-    if (rc != FBS_OK) return rc;
+    if (rc != FBS_OK) return scratch_fail(ctx, s, rc);
     return scratch_done(ctx, s);
 }
 
@@ -832,11 +958,11 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     }
     hipStream_t s = pick(ctx, stream);
     if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
-    if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return rc;
-    if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return rc;
+    if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return scratch_fail(ctx, s, rc);
+    if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return scratch_fail(ctx, s, rc);
     if (b.n_shared && (rc = dev_multi_extract(ctx, prog->tv, ctx->d_acc, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_row, b.d_x_table,
                                               b.d_x_dst, s)) != FBS_OK)
-        return rc;
+        return scratch_fail(ctx, s, rc);
     return scratch_done(ctx, s);
 }
 
@@ -875,15 +1001,9 @@ static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *c
     if (const char *cap = getenv("FBS_WIRE_BUDGET_MB")) have = std::min<size_t>(have, (size_t)std::max(1, atoi(cap)) << 20);
     const size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / per_sample));
     const size_t words = Tc * (size_t)prog->n_slots * ctw;
-    if (ctx->wires_capacity < words) {
-        if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));
-        if (ctx->d_wires) (void)hipFree(ctx->d_wires);
-        ctx->d_wires = nullptr;
-        ctx->wires_capacity = 0;
-        FBS_HIP(ctx, hipMalloc(&ctx->d_wires, words * 8));
-        ctx->wires_capacity = words;
-    }
-    int rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_sources) * Tc);
+    int rc = ensure_wires(ctx, words);
+    if (rc != FBS_OK) return rc;
+    rc = ensure_ms(ctx, (size_t)std::max(1u, prog->max_sources) * Tc);
     if (rc != FBS_OK) return rc;
     if (prog->max_shared && (rc = ensure_acc(ctx, (size_t)prog->max_shared * Tc)) != FBS_OK) return rc;
     *chunk = Tc;
@@ -960,32 +1080,71 @@ int fbs_profile_enable(fbs_ctx *ctx, int on) {
     return FBS_OK;
 }
 
-int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
-    if (!ctx) return FBS_E_INVALID;
+static int profile_collect(fbs_ctx *ctx) {
     FBS_HIP(ctx, hipSetDevice(ctx->device));
     for (int k = 0; k < 3; k++) {
         for (auto &pr : ctx->prof.pending[k]) {
-            FBS_HIP(ctx, hipEventSynchronize(pr.second));
+            FBS_HIP(ctx, hipEventSynchronize(pr.end));
             float t = 0;
-            FBS_HIP(ctx, hipEventElapsedTime(&t, pr.first, pr.second));
+            FBS_HIP(ctx, hipEventElapsedTime(&t, pr.begin, pr.end));
             ctx->prof.ms[k] += t;
             ctx->prof.launches[k]++;
-            ctx->prof.pool.push_back(pr);
+            Profile::PerKernel &pk = ctx->prof.by_kernel[k][pr.kernel];
+            pk.ms += t;
+            pk.launches++;
+            ctx->prof.pool.push_back({pr.begin, pr.end});
         }
         ctx->prof.pending[k].clear();
+    }
+    return FBS_OK;
+}
+
+int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
+    if (!ctx) return FBS_E_INVALID;
+    if (int rc = profile_collect(ctx)) return rc;
+    for (int k = 0; k < 3; k++) {
         if (ms) ms[k] = ctx->prof.ms[k];
         if (launches) launches[k] = ctx->prof.launches[k];
         if (reset) {
             ctx->prof.ms[k] = 0;
             ctx->prof.launches[k] = 0;
+            ctx->prof.by_kernel[k].clear();
         }
     }
+    return FBS_OK;
+}
+
+int fbs_profile_kernels(fbs_ctx *ctx, char *buf, size_t cap, size_t *needed) {
+    if (!ctx) return FBS_E_INVALID;
+    if (int rc = profile_collect(ctx)) return rc;
+    std::string text;
+    for (int k = 0; k < 3; k++)
+        for (const auto &kv : ctx->prof.by_kernel[k]) {
+            char line[64];
+            snprintf(line, sizeof line, "\t%llu\t%.6f\n", (unsigned long long)kv.second.launches, kv.second.ms);
+            text += std::to_string(k) + "\t" + kv.first + line;
+        }
+    if (needed) *needed = text.size() + 1;
+    if (!buf || cap < text.size() + 1) return buf ? set_error(ctx, FBS_E_INVALID, "buffer too small") : FBS_OK;
+    std::memcpy(buf, text.c_str(), text.size() + 1);
     return FBS_OK;
 }
 
 const char *fbs_profile_kernel(const fbs_ctx *ctx, int which) {
     if (!ctx || which < 0 || which > 2) return "";
     return ctx->prof.kernel[which].c_str();
+}
+
+const char *fbs_kernel_catalog(void) {
+    static const std::string text = [] {
+        std::vector<std::string> names;
+        keyswitch_catalog(&names);
+        blind_rotate_catalog(&names);
+        std::string t;
+        for (const std::string &n : names) t += n + "\n";
+        return t;
+    }();
+    return text.c_str();
 }
 
 int fbs_sync(fbs_ctx *ctx, void *stream) {

@@ -17,14 +17,10 @@ namespace fbs {
 namespace {
 struct ChaCha {
     uint32_t in[16];
-    ChaCha(uint64_t seed, uint64_t stream) {
+    ChaCha(const RandKey &key, uint64_t stream) {
         static const uint32_t sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
-        // key words 2..7 spell "fbs-exec-amd-gfx950-key1"
-        static const uint32_t tail[6] = {0x2d736266u, 0x63657865u, 0x646d612du, 0x7866672du, 0x2d303539u, 0x3179656bu};
         for (int i = 0; i < 4; i++) in[i] = sigma[i];
-        in[4] = (uint32_t)seed;
-        in[5] = (uint32_t)(seed >> 32);
-        for (int i = 0; i < 6; i++) in[6 + i] = tail[i];
+        for (int i = 0; i < 8; i++) in[4 + i] = key.w[i];
         in[12] = in[13] = 0;
         in[14] = (uint32_t)stream;
         in[15] = (uint32_t)(stream >> 32);
@@ -51,7 +47,39 @@ struct ChaCha {
 };
 }  // namespace
 
-void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count) {
+RandKey rand_key_from_seed64(uint64_t seed) {
+    // key words 2..7 spell "fbs-exec-amd-gfx950-key1"
+    static const uint32_t tail[6] = {0x2d736266u, 0x63657865u, 0x646d612du, 0x7866672du, 0x2d303539u, 0x3179656bu};
+    RandKey k;
+    k.w[0] = (uint32_t)seed;
+    k.w[1] = (uint32_t)(seed >> 32);
+    for (int i = 0; i < 6; i++) k.w[2 + i] = tail[i];
+    return k;
+}
+
+// 32 bytes of caller entropy -> the context's key: one ChaCha block under the caller's bytes, on a stream named by the
+// parameter set, so that contexts with different parameters under one seed share no key material (their secret keys would
+// otherwise be prefixes of each other).
+RandKey rand_key_derive(const uint8_t seed[32], const fbs_params &p) {
+    RandKey master;
+    std::memcpy(master.w, seed, 32);
+    uint64_t h = 0xcbf29ce484222325ull;   // FNV-1a over the fields that define the key material
+    const uint64_t fields[] = {p.n, p.log_n_poly, p.k, p.l_bsk, p.beta_bsk, p.t_ksk, p.gamma_ksk, p.p_msg, p.sigma_lwe, p.sigma_glwe,
+                               p.bsk_group == 2 ? 2u : 1u};
+    for (uint64_t f : fields)
+        for (int b = 0; b < 8; b++) {
+            h ^= (f >> (8 * b)) & 0xff;
+            h *= 0x100000001b3ull;
+        }
+    ChaCha c(master, (0xFFull << 56) | (h & 0x00FFFFFFFFFFFFFFull));
+    uint64_t blk[8];
+    c.block(0, blk);
+    RandKey k;
+    std::memcpy(k.w, blk, 32);
+    return k;
+}
+
+void rand_words(const RandKey &seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count) {
     ChaCha c(seed, stream);
     uint64_t blk[8];
     uint64_t have = ~0ull;
@@ -67,7 +95,7 @@ void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, si
 
 // Integer-only Gaussian stand-in (Irwin-Hall, 12 uniform 32-bit terms, variance 2^64), scaled by
 // sigma / 2^32 and rounded half-up.  Bounded at 6 sigma; fine for tests, not a production sampler.
-int64_t noise_sample(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t sigma) {
+int64_t noise_sample(const RandKey &seed, uint64_t stream, uint64_t idx, uint64_t sigma) {
     if (!sigma) return 0;
     uint64_t w[6];
     rand_words(seed, stream, idx * 6, w, 6);
@@ -103,9 +131,9 @@ void host_keygen(fbs_ctx *ctx) {
     ctx->sk_glwe.assign(D, 0);
     {
         std::vector<uint64_t> w(std::max(n, D));
-        rand_words(ctx->seed, stream_id(DOM_SK_LWE, 0), 0, w.data(), n);
+        rand_words(ctx->rkey, stream_id(DOM_SK_LWE, 0), 0, w.data(), n);
         for (uint32_t i = 0; i < n; i++) ctx->sk_lwe[i] = w[i] & 1;
-        rand_words(ctx->seed, stream_id(DOM_SK_GLWE, 0), 0, w.data(), D);
+        rand_words(ctx->rkey, stream_id(DOM_SK_GLWE, 0), 0, w.data(), D);
         for (uint32_t i = 0; i < D; i++) ctx->sk_glwe[i] = w[i] & 1;
     }
     // support of each GLWE key polynomial (binary key => A*S is a signed sum of shifted copies of A)
@@ -130,10 +158,10 @@ void host_keygen(fbs_ctx *ctx) {
             uint64_t *row = ctx->bsk.data() + r * row_words;
             uint64_t *body = row + (size_t)k * N;
             for (uint32_t j = 0; j < N; j++)
-                body[j] = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_BSK_NOISE, r), j, p.sigma_glwe));
+                body[j] = fq_from_i64(noise_sample(ctx->rkey, stream_id(DOM_BSK_NOISE, r), j, p.sigma_glwe));
             for (uint32_t c = 0; c < k; c++) {
                 uint64_t *a = row + (size_t)c * N;
-                rand_words(ctx->seed, stream_id(DOM_BSK_MASK, r), (uint64_t)c * N, a, N);
+                rand_words(ctx->rkey, stream_id(DOM_BSK_MASK, r), (uint64_t)c * N, a, N);
                 for (uint32_t j = 0; j < N; j++) a[j] = fq_fold(a[j]);
                 std::fill(prod.begin(), prod.end(), 0);
                 for (uint32_t sh : support[c]) {
@@ -152,8 +180,8 @@ void host_keygen(fbs_ctx *ctx) {
         for (size_t r = r0; r < r1; r++) {
             uint32_t j = (uint32_t)(r / t), v = (uint32_t)(r % t);
             uint64_t *row = ctx->ksk.data() + r * (n + 1);
-            rand_words(ctx->seed, stream_id(DOM_KSK_MASK, r), 0, row, n);
-            uint64_t b = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_KSK_NOISE, r), 0, p.sigma_lwe));
+            rand_words(ctx->rkey, stream_id(DOM_KSK_MASK, r), 0, row, n);
+            uint64_t b = fq_from_i64(noise_sample(ctx->rkey, stream_id(DOM_KSK_NOISE, r), 0, p.sigma_lwe));
             for (uint32_t i = 0; i < n; i++) {
                 row[i] = fq_fold(row[i]);
                 if (ctx->sk_lwe[i]) b = fq_add(b, row[i]);
@@ -173,8 +201,8 @@ void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_
     parallel_for(count, [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
             uint64_t *ct = cts + i * (D + 1);
-            rand_words(ctx->seed, stream_id(DOM_ENC_MASK, nonce0 + i), 0, ct, D);
-            uint64_t body = fq_from_i64(noise_sample(ctx->seed, stream_id(DOM_ENC_NOISE, nonce0 + i), 0, ctx->p.sigma_glwe));
+            rand_words(ctx->rkey, stream_id(DOM_ENC_MASK, nonce0 + i), 0, ct, D);
+            uint64_t body = fq_from_i64(noise_sample(ctx->rkey, stream_id(DOM_ENC_NOISE, nonce0 + i), 0, ctx->p.sigma_glwe));
             for (uint32_t j = 0; j < D; j++) {
                 ct[j] = fq_fold(ct[j]);
                 if (ctx->sk_glwe[j]) body = fq_add(body, ct[j]);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -18,8 +19,28 @@ enum Domain : uint64_t {
     DOM_KSK_MASK = 5, DOM_KSK_NOISE = 6, DOM_ENC_MASK = 7, DOM_ENC_NOISE = 8
 };
 inline uint64_t stream_id(Domain d, uint64_t sub) { return ((uint64_t)d << 56) | (sub & 0x00FFFFFFFFFFFFFFull); }
-void rand_words(uint64_t seed, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count);
-int64_t noise_sample(uint64_t seed, uint64_t stream, uint64_t idx, uint64_t sigma);
+// the 256-bit ChaCha key of a context: a 64-bit seed followed by a fixed tail (fbs_ctx_create: reproducible, test-grade), or
+// derived from 32 caller-supplied bytes and the parameter set (fbs_ctx_create_seeded)
+struct RandKey {
+    uint32_t w[8];
+};
+RandKey rand_key_from_seed64(uint64_t seed);
+RandKey rand_key_derive(const uint8_t seed[32], const fbs_params &p);
+void rand_words(const RandKey &key, uint64_t stream, uint64_t idx0, uint64_t *dst, size_t count);
+int64_t noise_sample(const RandKey &key, uint64_t stream, uint64_t idx, uint64_t sigma);
+
+// launcher knobs (fbs_ctx_tune): which kernel shape a launch takes.  Defaults are the measured choices; tests use them to reach
+// every launcher branch in one process, tools/ to measure one against another.
+struct Tune {
+    int64_t ks_gemm_min = 1;        // key switches per launch from which the int8 GEMM on the matrix cores is used
+    int64_t ks_mfma = 1;            // 0: never the GEMM
+    int64_t ks_fp = 1;              // 0: integer kernels instead of the FP64 one (fallback path)
+    int64_t ks_cols_major = 1;      // 0: round-1 grid order of the vector key-switch kernels
+    int64_t ks_split = 0;           // > 0: k slices of the GEMM
+    int64_t br_whole_cu = 1;        // 0: no whole-CU workgroups (four bootstraps per workgroup) in the blind rotation
+    int64_t br_cu_kernel = 1;       // 0: no one-bootstrap-per-CU kernel (the generic kernel on the four-wave transform instead)
+    int64_t br_cu_max_per_cu = 2;   // bootstraps per CU up to which a launch takes the one-bootstrap-per-CU kernel
+};
 
 // ---- launch descriptors ------------------------------------------------------------------------
 // A "gate" is one Bootstrap instruction applied to `s_count` samples of its source wire.  The bootstraps of a launch
@@ -49,12 +70,22 @@ struct GateView {
 };
 
 struct Profile {
+    struct Pending {
+        hipEvent_t begin, end;
+        std::string kernel;   // instantiation the bracketed launch used
+    };
+    struct PerKernel {
+        double ms = 0;
+        uint64_t launches = 0;
+    };
     bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[3];
+    std::vector<Pending> pending[3];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     double ms[3] = {0, 0, 0};
     uint64_t launches[3] = {0, 0, 0};
     std::string kernel[3];   // instantiation of the most recent launch of each kind
+    // the same totals per kernel instantiation: a launch that is cut into a whole-round part and a remainder shows as two entries
+    std::map<std::string, PerKernel> by_kernel[3];
 };
 
 }  // namespace fbs
@@ -62,6 +93,10 @@ struct Profile {
 struct fbs_ctx {
     fbs_params p{};
     uint64_t seed = 0;
+    fbs::RandKey rkey{};               // what all randomness of the context is expanded from
+    uint64_t next_nonce = 1ull << 55;  // fbs_encrypt_fresh: first unused encryption stream of [2^55, 2^56)
+    fbs::Tune tune;
+    int64_t scratch_growths = 0;       // how often a call had to (re)allocate scratch, i.e. blocked (fbs_ctx_stat)
     int device = 0;
     uint32_t N = 0, D = 0, rows = 0;   // D = k*N, rows = (k+1)*l
     uint32_t group = 1;                // key bits per blind-rotation step (1 or 2)
@@ -154,6 +189,8 @@ int dev_supported(const fbs_ctx *ctx);   // FBS_OK or error if no kernel instanc
 int dev_upload_keys(fbs_ctx *ctx);       // BSK -> NTT domain, KSK padded
 int dev_keyswitch_gemm_setup(fbs_ctx *ctx);   // limb fragments of the key-switching key for the int8 MFMA key switch
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream);
+int dev_keyswitch_reserve(fbs_ctx *ctx, size_t count);          // scratch of the GEMM key switch for launches of `count` (blocks when it grows)
+int dev_keyswitch_rezero(fbs_ctx *ctx, hipStream_t stream);     // puts its "zero between launches" scratch back after a failed call
 int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, const uint32_t *d_ms, hipStream_t stream);
 // `T` = sample stride of the wire buffer, samples [s_begin, s_begin + s_count) are computed
 int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, uint32_t n_out,
@@ -170,6 +207,9 @@ int dev_copy_out(fbs_ctx *ctx, const uint64_t *d_wires, size_t T, size_t s_begin
 int dev_multi_extract(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_acc_rows, uint64_t *d_wires, size_t T, size_t s_begin,
                       size_t s_count, uint32_t n_extract, const uint32_t *d_x_row, const uint32_t *d_x_table,
                       const uint32_t *d_x_dst, hipStream_t stream);
+// names of every kernel instantiation the launchers can pick (fbs_kernel_catalog)
+void blind_rotate_catalog(std::vector<std::string> *out);
+void keyswitch_catalog(std::vector<std::string> *out);
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream);
 
 // profiling helpers

@@ -642,7 +642,7 @@ void prof_begin(fbs_ctx *ctx, int, hipStream_t s, hipEvent_t *e0, hipEvent_t *e1
 void prof_end(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     if (!e0) return;
     (void)hipEventRecord(e1, s);
-    ctx->prof.pending[which].push_back({e0, e1});
+    ctx->prof.pending[which].push_back({e0, e1, ctx->prof.kernel[which]});
 }
 
 int dev_supported(const fbs_ctx *ctx) {
@@ -693,23 +693,44 @@ int dev_keyswitch_gemm_setup(fbs_ctx *ctx) {
 }
 
 // digits -> GEMM -> recombination + modulus switch, in passes of at most 8192 ciphertexts (the scratch stays bounded)
+constexpr size_t KS_GEMM_PASS = 8192;
+
+static bool keyswitch_gemm_exact(const fbs_ctx *ctx) {
+    // int8 GEMM on the matrix cores: exact while 2^(gamma-1) * 2^7 * kN t stays below 2^31
+    return ctx->d_ks_b && std::ldexp((double)ctx->D * ctx->p.t_ksk, (int)ctx->p.gamma_ksk + 6) < 2147483648.0;
+}
+
+int dev_keyswitch_reserve(fbs_ctx *ctx, size_t count) {
+    if (!keyswitch_gemm_exact(ctx)) return FBS_OK;
+    const KsGemm g = gemm_shape(ctx);
+    const size_t want = std::min<size_t>(KS_GEMM_PASS, (count + 127) / 128 * 128);
+    if (ctx->ks_rows_capacity >= want) return FBS_OK;
+    const uint32_t ldc = 6 * g.cols_pad;
+    ctx->scratch_growths++;
+    if (ctx->d_ks_a) (void)hipFree(ctx->d_ks_a);   // (hipFree waits for the kernels that may still use them)
+    if (ctx->d_ks_c) (void)hipFree(ctx->d_ks_c);
+    ctx->d_ks_a = nullptr;
+    ctx->d_ks_c = nullptr;
+    ctx->ks_rows_capacity = 0;
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ks_a, want * (size_t)g.ksteps * 32));
+    FBS_HIP(ctx, hipMalloc(&ctx->d_ks_c, want * (size_t)ldc * 4));
+    FBS_HIP(ctx, hipMemset(ctx->d_ks_c, 0, want * (size_t)ldc * 4));   // every launch leaves it zero again
+    FBS_HIP(ctx, hipDeviceSynchronize());
+    ctx->ks_rows_capacity = want;
+    return FBS_OK;
+}
+
+int dev_keyswitch_rezero(fbs_ctx *ctx, hipStream_t stream) {
+    if (ctx->d_ks_c && ctx->ks_rows_capacity)
+        FBS_HIP(ctx, hipMemsetAsync(ctx->d_ks_c, 0, ctx->ks_rows_capacity * (size_t)(6 * gemm_shape(ctx).cols_pad) * 4, stream));
+    return FBS_OK;
+}
+
 static int keyswitch_gemm(fbs_ctx *ctx, KsArgs &a, hipStream_t stream) {
     const KsGemm g = gemm_shape(ctx);
-    constexpr size_t PASS = 8192;
-    const size_t want = std::min<size_t>(PASS, (a.count + 127) / 128 * 128);
+    constexpr size_t PASS = KS_GEMM_PASS;
     const uint32_t ldc = 6 * g.cols_pad;
-    if (ctx->ks_rows_capacity < want) {
-        if (ctx->d_ks_a) (void)hipFree(ctx->d_ks_a);   // (hipFree waits for the kernels that may still use them)
-        if (ctx->d_ks_c) (void)hipFree(ctx->d_ks_c);
-        ctx->d_ks_a = nullptr;
-        ctx->d_ks_c = nullptr;
-        ctx->ks_rows_capacity = 0;
-        FBS_HIP(ctx, hipMalloc(&ctx->d_ks_a, want * (size_t)g.ksteps * 32));
-        FBS_HIP(ctx, hipMalloc(&ctx->d_ks_c, want * (size_t)ldc * 4));
-        FBS_HIP(ctx, hipMemset(ctx->d_ks_c, 0, want * (size_t)ldc * 4));   // every launch leaves it zero again
-        FBS_HIP(ctx, hipDeviceSynchronize());
-        ctx->ks_rows_capacity = want;
-    }
+    if (int rc = dev_keyswitch_reserve(ctx, a.count)) return rc;   // (a no-op after ensure_ms / fbs_ctx_reserve)
     ctx->prof.kernel[0] = "k_ks_gemm<2,2> (int8 MFMA)";
     for (size_t f0 = 0; f0 < a.count; f0 += PASS) {
         const size_t rows = std::min(PASS, a.count - f0);
@@ -719,7 +740,7 @@ static int keyswitch_gemm(fbs_ctx *ctx, KsArgs &a, hipStream_t stream) {
         // per wave halve the fragment traffic but leave one wave per SIMD: 186 against 135 us at N = 2048, t = 7.)
         const unsigned want_split = (2u * (unsigned)ctx->cu_count + m_blocks * n_blocks - 1) / (m_blocks * n_blocks);
         unsigned split = std::max(1u, std::min({want_split, 16u, g.ksteps / 16u}));
-        if (const char *e = getenv("FBS_KS_SPLIT")) split = std::max(1, atoi(e));   // (tuning)
+        if (ctx->tune.ks_split > 0) split = (unsigned)ctx->tune.ks_split;   // (tuning)
         const uint32_t klen = (g.ksteps + split - 1) / split;
         hipLaunchKernelGGL((k_ks_gemm<2, 2>), dim3(n_blocks, m_blocks, (g.ksteps + klen - 1) / klen), dim3(256), 0, stream,
                            reinterpret_cast<const v4i *>(ctx->d_ks_a), reinterpret_cast<const v4i *>(ctx->d_ks_b), ctx->d_ks_c, g.ksteps, klen,
@@ -728,6 +749,11 @@ static int keyswitch_gemm(fbs_ctx *ctx, KsArgs &a, hipStream_t stream) {
                            ctx->d_ks_c, ldc);
     }
     return FBS_OK;
+}
+
+void keyswitch_catalog(std::vector<std::string> *out) {
+    for (const char *k : {"k_ks_gemm<2,2> (int8 MFMA)", "k_keyswitch_fp<8,2,8>", "k_keyswitch_lanes<8,2,8>", "k_keyswitch_lanes<8,1,4>", "k_keyswitch<8>"})
+        out->push_back(k);
 }
 
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream) {
@@ -751,7 +777,15 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
     if (a.count == 0) return FBS_OK;
     hipEvent_t e0, e1;
     prof_begin(ctx, 0, stream, &e0, &e1);
-    if (a.count >= 32) {
+    // The int8 GEMM on the matrix cores serves every batch size (round 2 used it above 64 ciphertexts only; below, the integer
+    // kernels took 0.54 ms for 32-64 ciphertexts and 2.7 ms for 1-16, the GEMM takes 0.04-0.06 ms: its cost is streaming the
+    // key's 31 MB of limb fragments, whatever the number of rows).
+    const size_t gemm_min = (size_t)ctx->tune.ks_gemm_min;
+    const bool gemm_ok = ctx->tune.ks_mfma && keyswitch_gemm_exact(ctx);
+    if (a.count >= gemm_min && gemm_ok) {
+        const int rc = keyswitch_gemm(ctx, a, stream);
+        if (rc != FBS_OK) return rc;
+    } else if (a.count >= 32) {
         // lanes = ciphertexts: pays once a wave is at least half full
         constexpr int COLS = 8;
         // measured per 1024-batch: 64 ciphertexts x 4 waves 0.91 ms, 128 x 4 waves 0.81, 64 x 8 waves 1.10, 128 x 8 waves 0.65,
@@ -760,20 +794,15 @@ int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t 
         // multiple of 16 and dealt in adjacent pairs, XCD x only ever sees column blocks 2x, 2x+1 (mod 16): each key line is fetched by ONE XCD's L2
         // instead of all eight (the 50 MB key does not fit any L2), and what every XCD re-reads is the 8 times
         // smaller ciphertext batch.
-        static const bool cols_major = !(getenv("FBS_KS_TILES_MAJOR") && getenv("FBS_KS_TILES_MAJOR")[0] == '1');
+        const bool cols_major = ctx->tune.ks_cols_major != 0;
         a.cols_major = cols_major ? 1u : 0u;
         const unsigned cols = (p.n + 1 + COLS - 1) / COLS;
         const unsigned cols_padded = cols_major ? (cols + 15u) / 16u * 16u : cols;
         // FP64 form: needs the centred-double copy of the key and room to accumulate at least one mask word exactly
         const double per_word = (double)p.t_ksk * std::ldexp(1.0, 44 + (int)p.gamma_ksk);
         const double room = std::ldexp(1.0, 53) - std::ldexp(1.0, 45);
-        static const bool allow_fp = !(getenv("FBS_KS_INTEGER") && getenv("FBS_KS_INTEGER")[0] == '1');
-        // int8 GEMM on the matrix cores: exact while 2^(gamma-1) * 2^7 * kN t stays below 2^31
-        static const bool allow_gemm = !(getenv("FBS_KS_NO_MFMA") && getenv("FBS_KS_NO_MFMA")[0] == '1');
-        if (a.count > 64 && allow_gemm && ctx->d_ks_b && std::ldexp((double)ctx->D * p.t_ksk, (int)p.gamma_ksk + 6) < 2147483648.0) {
-            const int rc = keyswitch_gemm(ctx, a, stream);
-            if (rc != FBS_OK) return rc;
-        } else if (a.count > 64 && cols_major && allow_fp && ctx->d_ksk_f && per_word <= room) {
+        const bool allow_fp = ctx->tune.ks_fp != 0;
+        if (a.count > 64 && cols_major && allow_fp && ctx->d_ksk_f && per_word <= room) {
             const uint32_t words_per_fold = (uint32_t)std::min(1024.0, std::floor(room / per_word));
             const size_t tiles = (a.count + 127) / 128;
             for (size_t t0 = 0; t0 < tiles; t0 += 65535) {

@@ -5,6 +5,8 @@ over xGMI on MI355X; "gloo" in the CPU tests).  No counterpart in the reference,
 
 * `SampleShardedRunner` -- rank r evaluates the WHOLE program on its slice of the samples.  No data-path
   collective; outputs are all-gathered once at the end.
+* `ShardedRunner`       -- both at once: sample groups x gate groups, laid out by `choose_sharding` from the
+  program's level widths, T and the measured launch-time staircase.
 * `GateShardedRunner`   -- the wire buffer is replicated; at every level the flattened (gate, sample)
   batch is cut into G contiguous slices, rank r bootstraps slice r into a contiguous send buffer and ONE
   all-gather per level publishes the new ciphertexts, which a copy kernel then files into their wire slots
@@ -154,94 +156,188 @@ def _all_gather_rows(out, send, world, group):
         dist.all_gather(list(out.chunk(world)), send, group=group)
 
 
-class GateShardedRunner:
-    """Per-level all-gather.  Every rank calls `run` with the SAME input ciphertexts."""
+# --------------------------------------------------------------------------------------------
+# how to cut a program over G ranks
+# --------------------------------------------------------------------------------------------
+# One key switch + blind rotation launch of `count` bootstraps on one MI355X at the benchmark shape P1024, in ms
+# (profiles/r03/batch_sweep.txt).  Up to two bootstraps per CU a launch costs the latency of one or two bootstraps on a whole
+# CU (k_blind_rotate_cu), then the small workgroups, then whole rounds of four per CU; beyond a round, rounds + remainder.
+LAUNCH_MS_P1024 = ((1, 2.93), (128, 2.99), (256, 3.24), (257, 5.95), (512, 6.00), (513, 8.20), (768, 8.37), (769, 9.30), (1024, 9.50))
+ROUND_MS_P1024 = 9.30      # per further round of 1024 in a long launch (8192 bootstraps: 73.2 ms)
 
-    def __init__(self, backend, group=None, always_gather=False):
-        """always_gather: take the send-buffer / all-gather / scatter path even with a single rank (tests)."""
+
+def launch_ms(count, cost=1.0):
+    """Modelled time of one bootstrap launch of `count` ciphertexts; `cost` = params.bootstrap_cost of the parameter set."""
+    if count <= 0:
+        return 0.0
+    rounds, rest = divmod(int(count), 1024)
+    if rounds and rest >= 896:
+        rounds, rest = rounds + 1, 0
+    ms = rounds * ROUND_MS_P1024 + (0.2 if rounds == 1 and not rest else 0.0)
+    if rest:
+        xs, ys = zip(*LAUNCH_MS_P1024)
+        ms += float(np.interp(rest, xs, ys))
+    return ms * cost
+
+
+def allgather_ms(rows_per_rank, ranks, ct_bytes=8200, link_GBps=153.0, efficiency=0.8, latency_us=30.0):
+    """One all-gather of `rows_per_rank` ciphertexts from each of `ranks` GPUs over xGMI: every GPU receives ranks - 1 slices,
+    each over its own point-to-point link (at most 7 per GPU), so the time is one slice over one link, plus a fixed latency.
+    A model with its assumptions in the signature -- nothing here has been timed on more than one GPU."""
+    if ranks <= 1:
+        return 0.0
+    per_link = rows_per_rank * ct_bytes * -(-(ranks - 1) // min(ranks - 1, 7))
+    return latency_us * 1e-3 + per_link / (link_GBps * 1e9 * efficiency) * 1e3
+
+
+def choose_sharding(level_width, T, world, cost=1.0, ct_bytes=8200):
+    """How to lay `world` ranks over a program's two independent axes (fbs_mapper/fbs_exec_env.py:211-223): `sample_groups`
+    groups that each take a slice of the T samples through the whole program (no communication), times `gate_groups` ranks
+    per group that cut every level's (gate, sample) batch among themselves (one all-gather per level).
+
+    Per level every rank ends up with about width * T / world bootstraps whichever way the cut goes, so what decides is
+    (i) whether there are samples enough to cut (T < world forces gate groups), (ii) the collectives gate groups pay, and
+    (iii) how the slices fall on the launch-time staircase (`launch_ms`: a slice of 257 bootstraps costs two rounds of the
+    one-bootstrap-per-CU kernel, 256 cost one).  All divisor pairs of `world` are priced; ties go to fewer collectives.
+    -> dict(sample_groups, gate_groups, predicted_ms, single_gpu_ms, candidates)."""
+    level_width = [int(w) for w in level_width]
+    cands = []
+    for gs in range(1, world + 1):
+        if world % gs or gs > max(1, T):
+            continue
+        gg = world // gs
+        samples = -(-T // gs)
+        compute = sum(launch_ms(-(-w * samples // gg), cost) for w in level_width)
+        comm = sum(allgather_ms(-(-w * samples // gg), gg, ct_bytes) for w in level_width) if gg > 1 else 0.0
+        cands.append(dict(sample_groups=gs, gate_groups=gg, compute_ms=compute, allgather_ms=comm, predicted_ms=compute + comm))
+    best = min(cands, key=lambda c: (round(c["predicted_ms"], 6), c["gate_groups"]))
+    single = sum(launch_ms(w * T, cost) for w in level_width)
+    return dict(sample_groups=best["sample_groups"], gate_groups=best["gate_groups"], predicted_ms=best["predicted_ms"],
+                single_gpu_ms=single, predicted_speedup=single / best["predicted_ms"] if best["predicted_ms"] else 1.0, candidates=cands)
+
+
+# --------------------------------------------------------------------------------------------
+class ShardedRunner:
+    """`sample_groups` x `gate_groups` ranks (rank = sample group * gate_groups + position in its gate group).  A sample group
+    evaluates the whole program on its slice of the samples; inside it every level's flattened (gate, sample) batch is cut
+    into gate_groups contiguous slices, rank r bootstraps slice r into a contiguous send buffer, ONE all-gather per level
+    (within the group) publishes the new ciphertexts and a copy kernel files them into their wire slots.  sample_groups =
+    world is the sample-sharded mode (no data-path collective), sample_groups = 1 the gate-sharded one (north_star's shape);
+    `choose_sharding` picks.  Every rank calls `run` with the SAME input ciphertexts."""
+
+    def __init__(self, backend, group=None, sample_groups=None, always_gather=False):
+        """always_gather: take the send-buffer / all-gather / scatter path even with a single rank per gate group (tests)."""
         self.be, self.group, self.always_gather = backend, group, always_gather
+        self.rank, self.world = _world(group)
+        self.sample_groups = self.world if sample_groups is None else int(sample_groups)
+        if self.sample_groups < 1 or self.world % self.sample_groups:
+            raise ValueError("sample_groups must divide the number of ranks")
+        self.gate_groups = self.world // self.sample_groups
+        self.sg, self.gg = divmod(self.rank, self.gate_groups)
+        self.gate_group = group
+        if 1 < self.gate_groups < self.world:
+            # every rank creates every subgroup, in the same order (torch.distributed's rule); it keeps its own
+            for g in range(self.sample_groups):
+                ranks = list(range(g * self.gate_groups, (g + 1) * self.gate_groups))
+                sub = dist.new_group(ranks)
+                if g == self.sg:
+                    self.gate_group = sub
         self.collectives = 0
         self.bootstraps_done = 0
         self._bufs = None
+        self.time_collectives = False      # bench: bracket every all-gather with events on the current stream
+        self._events = []
 
-    def _buffers(self, T, world):
+    def collective_ms(self):
+        """Device time of the all-gathers since the last call (time_collectives = True), synchronising on them."""
+        ms = 0.0
+        for a, b in self._events:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+        self._events = []
+        return ms
+
+    def _gather(self, out, send, ranks, group):
+        if self.time_collectives and send.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _all_gather_rows(out, send, ranks, group)
+            b.record()
+            self._events.append((a, b))
+        else:
+            _all_gather_rows(out, send, ranks, group)
+        self.collectives += 1
+
+    def _buffers(self, Tr):
         be = self.be
-        chunk = max((-(-w * T // world) for w in be.level_width), default=1)
-        key = (T, world)
+        chunk = max((-(-w * Tr // self.gate_groups) for w in be.level_width), default=1)
+        key = (Tr, self.gate_groups)
         if self._bufs is None or self._bufs[0] != key:
-            gather = world > 1 or self.always_gather
-            self._bufs = (key, be.new_wires(T), be.new_rows(chunk), be.new_rows(chunk * world) if gather else None)
+            gather = self.gate_groups > 1 or self.always_gather
+            self._bufs = (key, be.new_wires(Tr), be.new_rows(chunk), be.new_rows(chunk * self.gate_groups) if gather else None)
         return self._bufs[1:]
 
-    def run_device(self, in_cts, T):
-        """Evaluate; returns the backend's output tensor [n_outputs, T, ctw] (constant outputs zero)."""
-        be = self.be
-        rank, world = _world(self.group)
-        wires, send, gathered = self._buffers(T, world)
-        be.load_inputs(wires, T, in_cts, T)
-        for L in range(be.depth + 1):
-            be.lincomb_level(wires, T, L, T)                  # cheap, done redundantly on every rank
-            if L == be.depth:
-                break
-            total = be.level_width[L] * T
-            f0, f1, chunk = split_range(total, world, rank)
-            self.bootstraps_done += f1 - f0
-            if world == 1 and not self.always_gather:
-                be.bootstrap_level(wires, T, L, T, f0, f1)    # straight into the wire slots
-                continue
-            be.bootstrap_level(wires, T, L, T, f0, f1, send)
-            _all_gather_rows(gathered[:world * chunk], send[:chunk], world, self.group)
-            self.collectives += 1
-            be.scatter_level(wires, T, L, T, gathered, 0, total)   # slices are contiguous: rank r's rows start at r*chunk
-        return be.read_outputs(wires, T, T)
-
-    def run(self, in_cts, T):
-        out = self.run_device(in_cts, T)
-        return out.cpu().numpy().view(np.uint64)
-
-
-class SampleShardedRunner:
-    """Whole program per rank on a slice of the samples; one all-gather of the outputs at the end."""
-
-    def __init__(self, backend, group=None):
-        self.be, self.group = backend, group
-        self.collectives = 0
-        self.bootstraps_done = 0
-
     def run_local(self, in_cts, T):
-        """This rank's share: -> (device tensor [n_outputs, chunk, ctw] of which the first s1-s0 samples are valid, s0, s1)"""
+        """This rank's share: -> (backend tensor [n_outputs, chunk, ctw] of which the first s1 - s0 samples are valid, s0, s1);
+        complete on every rank of a sample group."""
         be = self.be
-        rank, world = _world(self.group)
-        s0, s1, chunk = split_range(T, world, rank)
+        s0, s1, chunk = split_range(T, self.sample_groups, self.sg)
         Tr, cnt = max(1, chunk), s1 - s0
-        wires = be.new_wires(Tr)
+        wires, send, gathered = self._buffers(Tr)
         if cnt:
             local = in_cts.reshape(be.n_inputs, T, be.ctw)[:, s0:s1]
             be.load_inputs(wires, Tr, local if torch.is_tensor(local) else np.ascontiguousarray(local), cnt)
         for L in range(be.depth + 1):
-            be.lincomb_level(wires, Tr, L, cnt)
-            if L < be.depth:
-                be.bootstrap_level(wires, Tr, L, cnt, 0, be.level_width[L] * cnt)
-                self.bootstraps_done += be.level_width[L] * cnt
-        out = be.read_outputs(wires, Tr, Tr)
-        return out, s0, s1
+            be.lincomb_level(wires, Tr, L, cnt)              # cheap, done redundantly on every rank of the group
+            if L == be.depth:
+                break
+            total = be.level_width[L] * cnt
+            f0, f1, rows = split_range(total, self.gate_groups, self.gg)
+            self.bootstraps_done += f1 - f0
+            if self.gate_groups == 1 and not self.always_gather:
+                be.bootstrap_level(wires, Tr, L, cnt, f0, f1)    # straight into the wire slots
+                continue
+            if total == 0:
+                continue
+            be.bootstrap_level(wires, Tr, L, cnt, f0, f1, send)
+            self._gather(gathered[:self.gate_groups * rows], send[:rows], self.gate_groups, self.gate_group)
+            be.scatter_level(wires, Tr, L, cnt, gathered, 0, total)   # slices are contiguous: rank r's rows start at r * rows
+        return be.read_outputs(wires, Tr, Tr), s0, s1
+
+    def run_device(self, in_cts, T):
+        """Gate-sharded use (sample_groups = 1): the backend's output tensor [n_outputs, T, ctw] (constant outputs zero)."""
+        if self.sample_groups != 1:
+            raise ValueError("run_device returns whole outputs: it is for sample_groups = 1 (use run or run_local)")
+        return self.run_local(in_cts, T)[0]
 
     def run(self, in_cts, T):
+        """-> host array [n_outputs, T, ctw], the same on every rank."""
         be = self.be
-        rank, world = _world(self.group)
         in_cts = in_cts if torch.is_tensor(in_cts) else np.asarray(in_cts)
         send, s0, s1 = self.run_local(in_cts, T)
+        if self.sample_groups == 1:
+            return send.cpu().numpy().view(np.uint64)[:, :T]
         n_out, Tr = send.shape[0], send.shape[1]
-        send = send.reshape(n_out * Tr, be.ctw)
-        if world > 1:
-            gathered = torch.empty((world * n_out * Tr, be.ctw), dtype=send.dtype, device=send.device)
-            _all_gather_rows(gathered, send.contiguous(), world, self.group)
-            self.collectives += 1
-        else:
-            gathered = send
-        g = gathered.cpu().numpy().view(np.uint64).reshape(world, n_out, Tr, be.ctw)
+        send = send.reshape(n_out * Tr, be.ctw).contiguous()
+        gathered = torch.empty((self.world * n_out * Tr, be.ctw), dtype=send.dtype, device=send.device)
+        self._gather(gathered, send, self.world, self.group)          # one gather of the outputs at the very end
+        g = gathered.cpu().numpy().view(np.uint64).reshape(self.world, n_out, Tr, be.ctw)
         out = np.zeros((n_out, T, be.ctw), np.uint64)
-        for r in range(world):
-            a, b_, _ = split_range(T, world, r)
-            out[:, a:b_] = g[r, :, :b_ - a]
+        for sg in range(self.sample_groups):
+            a, b_, _ = split_range(T, self.sample_groups, sg)
+            out[:, a:b_] = g[sg * self.gate_groups, :, :b_ - a]      # (every rank of a sample group holds the group's outputs)
         return out
+
+
+class GateShardedRunner(ShardedRunner):
+    """Per-level all-gather over all ranks (sample_groups = 1)."""
+
+    def __init__(self, backend, group=None, always_gather=False):
+        super().__init__(backend, group, sample_groups=1, always_gather=always_gather)
+
+
+class SampleShardedRunner(ShardedRunner):
+    """Whole program per rank on a slice of the samples; one all-gather of the outputs at the end."""
+
+    def __init__(self, backend, group=None):
+        super().__init__(backend, group, sample_groups=None)

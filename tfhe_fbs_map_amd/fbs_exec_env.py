@@ -21,6 +21,7 @@ The north-star name `FbsExecEnv` is an alias of `LutExecEnv`.
 from __future__ import annotations
 
 import logging
+import math
 import os
 import re
 import sys
@@ -89,13 +90,22 @@ class ExecConfig:
     parameter set that is 128-bit secure (noise from `params.sigma_min`) and leaves `min_margin`
     standard deviations of room at the program's own (p, norm2_linprod) -- the role of the patched
     optimizer in the reference's flow (experiments/add_exec_estimates.py:9-16).  Pass `params`
-    explicitly (e.g. `params.P1024`, the reduced-noise benchmark set) to override."""
+    explicitly (e.g. `params.P1024`, the reduced-noise benchmark set) to override.
+
+    What "128-bit" covers: the NOISE LEVELS of the chosen set (params.sigma_min).  The randomness behind them is test-grade
+    (`_native.RANDOMNESS_GRADE`: ChaCha20 streams, an Irwin-Hall stand-in for the discrete Gaussian); with `seed=None` the
+    generator is keyed with 256 bits from the OS and the parameter set is mixed into the derivation, with an int seed it is
+    the reproducible 64-bit form tests use.  A deployment brings its own keys: `Context.import_keys`."""
     fbs_size: int | None = None
     params: object | None = None          # tfhe_fbs_map_amd.Params (p_msg is overridden by fbs_size)
-    seed: int | None = None               # key seed; None = drawn from os.urandom once per ExecConfig
+    seed: int | bytes | None = None       # key seed: int = reproducible (tests); None = 32 bytes from os.urandom, once per ExecConfig
     device: int = 0
-    nonce0: int | None = None             # first encryption nonce; None = a counter that advances with every eval()
+    nonce0: int | None = None             # first encryption nonce (reproducible runs); None = streams nobody has used (the context counts)
     min_margin: float = 6.0               # p_error ~ 2e-9 per bootstrap (the reference's optimizer default is 4 sigma)
+    # Where nothing reaches `min_margin` at N <= 4096 the selector raises.  Set this (e.g. params.REFERENCE_MARGIN = 4.0, the
+    # reference optimizer's own default, p_error 6e-5 per bootstrap) to let it step down to that floor instead; the margin a
+    # program actually got and what it means for the whole program is in `last_choice` either way.
+    allow_margin_floor: float | None = None
     security: int = 128
     reduced_noise: bool = False           # params=None: the reduced-noise benchmark set for p (params.params_for) -- NOT secure
     # Several tables on one linear combination (the reference's one-gate-one-bootstrap lowering, map_to_fbs.py:41-45): share
@@ -106,11 +116,11 @@ class ExecConfig:
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)
-    _next_nonce: int = field(default=0, repr=False)
+    last_choice: dict | None = field(default=None, repr=False)   # what `choose` decided for the most recent program
 
     def key_seed(self):
         if self.seed is None:
-            self.seed = int.from_bytes(os.urandom(8), "little")
+            self.seed = os.urandom(32)
         return self.seed
 
     def params_choice(self, p, norm2=1):
@@ -119,8 +129,14 @@ class ExecConfig:
         if self.params is None and self.reduced_noise:
             return params_for(p)
         if self.params is None:
-            return choose_params(p, norm2, min_margin=self.min_margin, security=self.security,
-                                 floor_margin=min(self.min_margin, REFERENCE_MARGIN))
+            floor = None if self.allow_margin_floor is None else min(self.min_margin, self.allow_margin_floor)
+            try:
+                return choose_params(p, norm2, min_margin=self.min_margin, security=self.security, floor_margin=floor)
+            except ValueError as e:
+                if floor is not None:
+                    raise
+                raise ValueError("%s; ExecConfig(allow_margin_floor=%.1f) accepts the reference optimizer's own %.1f sigma "
+                                 "(p_error 6.3e-5 per bootstrap)" % (e, REFERENCE_MARGIN, REFERENCE_MARGIN)) from None
         return self.params.replace(p_msg=p)
 
     def context_of(self, prm):
@@ -136,18 +152,29 @@ class ExecConfig:
 
     def choose(self, env, p):
         """(context, fuse) for a program: the parameter set of `params_choice` at the program's norm, and whether the
-        tables of shared sources share their blind rotation (`fuse_tables`)."""
+        tables of shared sources share their blind rotation (`fuse_tables`).  Leaves in `last_choice` the margin the
+        program got and the failure probability that goes with it."""
         from .params import bootstrap_cost
         stats = env.stats()
         fstats = env.fusion_stats(p) if self.fuse_tables is not False else None
         if fstats is None or fstats["nb_rotation"] == stats["nb_bootstrap"] or (self.fuse_tables is None and self.params is not None):
-            return self.context_for(p, stats["norm2_linprod"]), False
+            return self._chosen(self.params_choice(p, stats["norm2_linprod"]), False, stats["norm2_linprod"], stats["nb_bootstrap"])
         fused = self.params_choice(p, fstats["norm2_linprod"])
-        if self.fuse_tables is True:
-            return self.context_of(fused), True
-        plain = self.params_choice(p, stats["norm2_linprod"])
-        cheaper = bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]
-        return (self.context_of(fused), True) if cheaper else (self.context_of(plain), False)
+        if self.fuse_tables is not True:
+            plain = self.params_choice(p, stats["norm2_linprod"])
+            if not bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]:
+                return self._chosen(plain, False, stats["norm2_linprod"], stats["nb_bootstrap"])
+        return self._chosen(fused, True, fstats["norm2_linprod"], stats["nb_bootstrap"])
+
+    def _chosen(self, prm, fuse, norm2, nb_bootstrap):
+        from .params import margin_sigmas, p_error
+        margin = margin_sigmas(prm, norm2)
+        per_bootstrap = p_error(margin)
+        self.last_choice = dict(params=prm, fuse_tables=fuse, norm2=norm2, margin_sigmas=margin, asked_margin=self.min_margin,
+                                p_error_per_bootstrap=per_bootstrap,
+                                p_error_per_sample=-math.expm1(nb_bootstrap * math.log1p(-min(per_bootstrap, 0.5))),
+                                relaxed=self.params is None and not self.reduced_noise and margin < self.min_margin - 1e-9)
+        return self.context_of(prm), fuse
 
     def program_for(self, ctx, low, fuse=False):
         """The loaded (device-resident) form of a lowered program, cached; the cache is bounded because every entry
@@ -168,12 +195,9 @@ class ExecConfig:
         return prog
 
     def take_nonces(self, count):
-        """Every ciphertext ever encrypted under one ExecConfig gets its own randomness stream."""
-        if self.nonce0 is not None:
-            return self.nonce0
-        first = self._next_nonce
-        self._next_nonce += count
-        return first
+        """Every ciphertext ever encrypted under one ExecConfig gets its own randomness stream: None = the context hands out
+        streams nobody has used (fbs_encrypt_fresh); an explicit `nonce0` pins them for reproducible runs."""
+        return self.nonce0
 
 
 class LutExecEnv:

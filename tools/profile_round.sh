@@ -1,16 +1,18 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/rNN: kernel-trace stats, then PMC counters in their own passes (no trace domains mixed
-# in), for the headline batch (bench.py, P1024) and for the 128-bit parameter set (tools/secure_bench.py); summarised per
-# kernel by tools/profile_summary.py.
-#   usage (on the GPU box): bash tools/profile_round.sh [tag]      -> gpurun_out/prof_<tag>/{p1024,secure}/
-TAG=${1:-r02}
+# in), for a list of (name, command) sets; summarised per kernel by tools/profile_summary.py.
+#   usage (on the GPU box): bash tools/profile_round.sh <tag> [set ...]      -> gpurun_out/prof_<tag>/<set>/
+#   sets: p1024 (bench.py headline), cu256 (bench.py --batch 256: one bootstrap per CU), secure (128-bit p = 15, two key bits per
+#         step), secure1 (one key bit per step), p31 (config 5: 128-bit set for p = 31), p63 (N = 4096), p4 (N = 1024 128-bit set)
+TAG=${1:-r03}; shift
+SETS=${@:-p1024 cu256 secure p31}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TOP=gpurun_out/prof_$TAG
-rm -rf $TOP && mkdir -p $TOP
-PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES")
+mkdir -p $TOP
+PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_LDS_IDX_ACTIVE")
 run_set() {   # $1 = subdir, rest = command
   local OUT=$TOP/$1; shift
-  mkdir -p $OUT
+  rm -rf $OUT && mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- "$@" > $OUT/under_rocprof.out 2> $OUT/under_rocprof.err
   local i=0
   for c in "${PMCS[@]}"; do
@@ -18,8 +20,17 @@ run_set() {   # $1 = subdir, rest = command
     rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$i -- "$@" > /dev/null 2> $OUT/pmc_$i.err
   done
   python3 tools/profile_summary.py $OUT > $OUT/summary.json
+  cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+  echo "set $1 done"
 }
-run_set p1024 python3 bench.py --steps 10 --cpu-sample 0 --no-secure
-run_set secure python3 tools/secure_bench.py 1024 5
-python3 bench.py > $TOP/bench.json 2> $TOP/bench.err
-tail -c 400 $TOP/bench.json
+for S in $SETS; do
+  case $S in
+    p1024)   run_set p1024 python3 bench.py --steps 10 --cpu-sample 0 --no-secure ;;
+    cu256)   run_set cu256 python3 bench.py --batch 256 --steps 10 --cpu-sample 0 --no-secure ;;
+    secure)  run_set secure python3 tools/secure_bench.py 1024 5 15 70 ;;
+    secure1) run_set secure1 python3 tools/secure_bench.py 1024 5 15 70 1 ;;
+    p31)     run_set p31 python3 tools/secure_bench.py 1024 4 31 325 ;;
+    p63)     run_set p63 python3 tools/secure_bench.py 1024 3 63 100 ;;
+    p4)      run_set p4 python3 tools/secure_bench.py 1024 5 4 2 ;;
+  esac
+done

@@ -1,5 +1,5 @@
-"""The 128-bit-secure parameter set for p = 15 (params.choose_params(15, 70)) on a flat batch: the kernel the `secure`
-leg of bench.py times, alone, for rocprofv3 --pmc passes."""
+"""A 128-bit-secure parameter set (params.choose_params(p, norm2); default p = 15, norm2 = 70: what the `secure` leg of bench.py
+times) on a flat batch, alone, for rocprofv3 --pmc passes:  secure_bench.py [batch] [steps] [p] [norm2] [key bits per step]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,12 +8,14 @@ from tfhe_fbs_map_amd import Context, choose_params
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-prm = choose_params(15, 70)
+p_msg = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+norm2 = float(sys.argv[4]) if len(sys.argv) > 4 else 70
+prm = choose_params(p_msg, norm2, groups=(int(sys.argv[5]),)) if len(sys.argv) > 5 else choose_params(p_msg, norm2)
 ctx = Context(prm, seed=1)
 rng = np.random.default_rng(42)
-tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
+tables = [[0] + [int(v) for v in rng.integers(0, 2, p_msg - 1)] for _ in range(16)]
 tv = ctx.tvset(tables)
-msgs = rng.integers(0, 15, B)
+msgs = rng.integers(0, p_msg, B)
 ids = (np.arange(B) % 16).astype(np.uint32)
 d_in = torch.from_numpy(ctx.encrypt(msgs, nonce0=0).view(np.int64)).cuda()
 d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
