@@ -260,3 +260,30 @@ def test_ciphertext_kats():
         got = mod.batch_case(name, prm)
         assert got == want["kats"][name], name
     assert mod.fused_case() == want["kats"]["fused_adder8"]
+
+
+def test_tuned_baseline_equals_the_oracle():
+    """oracle/tfhe_tuned.c (AVX-512 IFMA, eight bootstraps per vector) is what bench.py prints as the TUNED CPU baseline; it is
+    not the checker, and it is held to the checker here: every word equal, three shapes, every table mode, trivial and
+    maximal ciphertexts, a batch that is not a multiple of eight."""
+    from oracle import tfhe_tuned
+    from tfhe_fbs_map_amd import Params
+    if not tfhe_tuned.supported():
+        pytest.skip("this CPU has no AVX-512 IFMA")
+    for prm in (Params(n=12, log_n_poly=10, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 8),
+                Params(n=8, log_n_poly=8, l_bsk=2, beta_bsk=9, t_ksk=5, gamma_ksk=3, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 8),
+                Params(n=6, log_n_poly=11, l_bsk=1, beta_bsk=20, t_ksk=16, gamma_ksk=1, p_msg=7, sigma_lwe=1 << 8, sigma_glwe=1 << 4)):
+        o = orc.Oracle(prm, seed=9)
+        t = tfhe_tuned.Tuned(o)
+        msgs = np.concatenate([np.arange(len(tb)) for tb in TABLES_ALL_MODES])
+        ids = np.concatenate([np.full(len(tb), i) for i, tb in enumerate(TABLES_ALL_MODES)]).astype(np.uint32)
+        msgs, ids = msgs[:-3], ids[:-3]                       # not a multiple of eight: the last group is short
+        cts = o.encrypt(msgs, nonce0=3)
+        cts[2, :-1] = 0
+        cts[5, :] = orc.Q - 1
+        assert len(cts) % 8
+        ref, _ = o.bootstrap_batch(cts, TABLES_ALL_MODES, ids)
+        got, _ = t.bootstrap_batch(cts, TABLES_ALL_MODES, ids, threads=2)
+        assert np.array_equal(got, ref), prm
+    with pytest.raises(ValueError):
+        tfhe_tuned.Tuned(orc.Oracle(Params(n=8, log_n_poly=10, l_bsk=1, beta_bsk=20, p_msg=7, bsk_group=2), seed=1))

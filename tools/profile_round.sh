@@ -11,6 +11,7 @@ TOP=gpurun_out/prof_$TAG
 mkdir -p $TOP
 PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_LDS_IDX_ACTIVE")
 run_set() {   # $1 = subdir, rest = command
+  local NAME=$1
   local OUT=$TOP/$1; shift
   rm -rf $OUT && mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- "$@" > $OUT/under_rocprof.out 2> $OUT/under_rocprof.err
@@ -21,7 +22,7 @@ run_set() {   # $1 = subdir, rest = command
   done
   python3 tools/profile_summary.py $OUT > $OUT/summary.json
   cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
-  echo "set $1 done"
+  echo "set $NAME done"
 }
 for S in $SETS; do
   case $S in

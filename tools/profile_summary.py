@@ -12,7 +12,8 @@ root = sys.argv[1]
 
 def short(name):
     m = re.search(r"(k_[a-z_]+)\s*(<[^>]*>)?", name)
-    return (m.group(1) + (m.group(2) or "")).replace(" ", "") if m else name
+    # (the kernel trace prints defaulted template arguments: k_blind_rotate<10,6,3,4,true> is the launcher's k_blind_rotate<10,6,3,4>)
+    return (m.group(1) + (m.group(2) or "")).replace(" ", "").replace(",true>", ">") if m else name
 
 
 out = collections.defaultdict(dict)
