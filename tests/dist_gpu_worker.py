@@ -17,10 +17,11 @@ from tests.helpers import load_fixture, subsample      # noqa: E402
 
 def main():
     name, T, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    from tfhe_fbs_map_amd import Context, Params, Program, parse_fbs
+    from tfhe_fbs_map_amd import Context, FbsError, Params, Program, parse_fbs
     from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend, SampleShardedRunner
     rec = load_fixture(name)
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
@@ -29,18 +30,28 @@ def main():
     prm = Params(n=12, log_n_poly=10, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=1 << 8)
     ctx = Context(prm, seed=21)                       # keys replicated: every rank derives them from the seed
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
-                   low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+                   low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fused)
     ins, expect = subsample(rec, T)
     cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=7)
     res = {}
     for mode, cls in (("gate", GateShardedRunner), ("sample", SampleShardedRunner)):
         runner = cls(GpuBackend(prog))
+        if fused and mode == "gate" and prog.n_rotations < prog.n_bootstrap:
+            # a level with shared rotations runs whole: cutting it across ranks is refused, cleanly, on every rank
+            try:
+                runner.run(cts, T)
+                raise SystemExit("slicing a fused level was not refused")
+            except FbsError as e:
+                assert "fused" in str(e)
+            res[mode], res[mode + "_collectives"], res[mode + "_fbs"] = np.zeros(0), -1, 0
+            continue
         res[mode] = runner.run(cts, T)
         res[mode + "_collectives"] = runner.collectives
         res[mode + "_fbs"] = runner.bootstraps_done
     if rank == 0:
         ref = prog.eval(cts, T)                       # the single-process answer
-        np.savez(out_path, gate=res["gate"], sample=res["sample"], ref=ref, dec=ctx.decrypt(res["gate"]), world=world,
+        np.savez(out_path, gate=res["gate"], sample=res["sample"], ref=ref, dec=ctx.decrypt(res["gate"]) if res["gate"].size else np.zeros(0),
+                 dec_sample=ctx.decrypt(res["sample"]), world=world,
                  gate_collectives=res["gate_collectives"], sample_collectives=res["sample_collectives"],
                  gate_fbs=res["gate_fbs"], sample_fbs=res["sample_fbs"], depth=prog.depth, n_bootstrap=prog.n_bootstrap)
     dist.barrier()

@@ -41,3 +41,30 @@ def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T):
     assert int(z["gate_collectives"]) == int(z["depth"]) and int(z["sample_collectives"]) == 1
     total = int(z["n_bootstrap"]) * T
     assert total // 2 - int(z["depth"]) <= int(z["gate_fbs"]) <= -(-total // 2) + int(z["depth"])      # rank 0 did half
+
+
+def test_two_ranks_on_a_fused_program(tmp_path):
+    """A program loaded with FBS_LOAD_FUSE_TABLES (several tables on one blind rotation): the sample-sharded layout works
+    unchanged and returns the single-process ciphertexts; cutting its levels across ranks is refused with an error that
+    says why (a shared rotation's tables are cut from one accumulator)."""
+    name, T = "adder8__basic_p2", 4
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    out = str(tmp_path / "res.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(T), out, "fused"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    z = np.load(out)
+    rec = load_fixture(name)
+    _, expect = subsample(rec, T)
+    low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
+    assert int(z["gate_collectives"]) == -1 and int(z["sample_collectives"]) == 1
+    for k, w in enumerate(low["out_wire"]):
+        if w >= 0:
+            assert np.array_equal(z["sample"][k], z["ref"][k])
+            assert np.array_equal(ctx_free_decrypt(z, k), expect[low["out_names"][k]])
+
+
+def ctx_free_decrypt(z, k):
+    return z["dec_sample"][k]

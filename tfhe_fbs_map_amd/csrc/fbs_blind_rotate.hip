@@ -78,9 +78,6 @@ __global__ __launch_bounds__(1 << LL) void k_polymul(const uint64_t *a, const ui
 // long; small workgroups of a long launch are refilled as they finish and do better left alone -- and the mere presence of
 // s_setprio costs the compiler's schedule 7 % there (N = 1024, l = 2, 8192 bootstraps: 118 k FBS/s with, 134 k without;
 // 1024 bootstraps: 129 against 125), so the launcher picks an instantiation, not a flag.
-#ifndef FBS_STASH_DIGITS
-#define FBS_STASH_DIGITS 1
-#endif
 template <int LOGN, int LL, int DIG, int FPW, bool TURNS = true>
 __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu(2))) void k_blind_rotate(BrArgs a) {
     using W = typename NttFor<LOGN, LL>::type;
@@ -94,11 +91,6 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     constexpr bool PEEL = ONE_LEVEL || TWO_LEVELS || LL <= FBS_PEEL_MAX_LL;
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds_all[FPW * 2 * 2 * N];   // [bootstrap][component][ping-pong][N]
-    // Two levels on polynomials spread over several waves (the 128-bit sets for p = 31 at N = 2048 and p = 63 at N = 4096): the
-    // packed digit words wait for the second level in LDS instead of in registers the first level's transform and products
-    // need (the compiler spilled 13 / 26 registers to scratch memory; each thread reads back what it wrote, no synchronisation)
-    constexpr bool STASH = TWO_LEVELS && LL >= 7 && FBS_STASH_DIGITS;
-    __shared__ uint32_t stash_all[STASH ? FPW * (2 << LL) * E : 1];
     const uint32_t sub = threadIdx.x >> (LL + 1);          // which bootstrap of the workgroup
     const uint32_t comp = (threadIdx.x >> LL) & 1u;        // GLWE component owned by this thread: 0 = mask, 1 = body
     const uint32_t t = threadIdx.x & (LANES - 1);
@@ -244,15 +236,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             }
         };
         if constexpr (TWO_LEVELS) {
-            if constexpr (STASH) {
-#pragma unroll
-                for (int m = 0; m < E; m++) stash_all[(uint32_t)m * (FPW * (2 << LL)) + threadIdx.x] = digits[m];
-            }
             level(1, std::true_type{});
-            if constexpr (STASH) {
-#pragma unroll
-                for (int m = 0; m < E; m++) digits[m] = stash_all[(uint32_t)m * (FPW * (2 << LL)) + threadIdx.x];
-            }
             level(0, std::false_type{});
         } else if constexpr (PEEL) {
             level((int)a.l - 1, std::true_type{});

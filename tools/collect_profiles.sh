@@ -1,0 +1,22 @@
+#!/bin/bash
+# gpurun_out/prof_<tag>/ (tools/profile_round.sh) -> profiles/<round>/: per-set summaries + kernel-trace stats, and the PMC record
+# bench.py reads (stamped with the SHA-256 of the kernel sources as they are NOW: run right after the profile round).
+#   usage (here, after the gpurun call merged its outputs): bash tools/collect_profiles.sh r03 r03
+TAG=${1:-r03}; ROUND=${2:-r03}
+SRC=gpurun_out/prof_$TAG; DST=profiles/$ROUND
+mkdir -p $DST
+rm -f $DST/pmc_blind_rotate.json
+for S in $(ls $SRC); do
+  [ -f $SRC/$S/summary.json ] || continue
+  cp $SRC/$S/summary.json $DST/summary_$S.json
+  [ -f $SRC/$S/kernel_stats.csv ] && cp $SRC/$S/kernel_stats.csv $DST/kernel_stats_$S.csv
+done
+[ -f $SRC/bench.json ] && cp $SRC/bench.json $DST/bench.json
+rec() { [ -f $DST/summary_$1.json ] && python3 tools/make_pmc_record.py $DST/summary_$1.json $2 $3 $DST/pmc_blind_rotate.json $4 profiles/$ROUND/summary_$1.json; }
+rec p1024 630 1 1024
+rec cu256 630 1 256
+rec secure 714 2 1024
+rec secure1 710 1 1024
+rec p31 766 1 1024
+rec p63 822 1 1024
+rec p4 638 1 1024
