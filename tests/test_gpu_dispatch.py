@@ -37,9 +37,9 @@ def recipe(name):
             count = 4 * CUS
         elif fpw == 2:                                    # between one and two bootstraps per CU, two per workgroup
             count, knobs = CUS + 44, dict(br_cu_kernel=0)
-        elif LL != main_ll:                               # N = 1024 on four waves per polynomial, generic kernel
+        elif LL != main_ll:                               # N = 1024 / 2048 on four waves per polynomial, generic kernel
             count, knobs = 40, dict(br_cu_kernel=0)
-        elif L == 10:                                     # small workgroups: neither a whole round nor at most two per CU
+        elif L in (10, 11):                               # main shape: more than two bootstraps per CU (below, the one-per-CU shapes)
             count = 2 * CUS + 88
         else:
             count = 40
@@ -49,13 +49,13 @@ def recipe(name):
         L, dig = int(m.group(1)), int(m.group(3))
         l, beta = {4: (1, 20), 3: (2, 7), 0: (2, 10)}[dig]
         return dict(log_n=L, l=l, beta=beta, group=2, count=40, knobs={})
-    m = re.fullmatch(r"k_blind_rotate_cu<10,(\d+),(\d+)>", name)
+    m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)>", name)
     if m:
-        nl, first = int(m.group(1)), int(m.group(2))
+        L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))
         beta = {2: 7, 1: 9, 0: 10}[first]
         if nl * beta > 30:
             beta = 30 // nl
-        return dict(log_n=10, l=nl, beta=beta, group=1, count=CUS + 3 if nl == 3 else 40, knobs={})
+        return dict(log_n=L, l=nl, beta=beta, group=1, count=CUS + 3 if nl == 3 or (L, nl) == (11, 2) else 40, knobs={})
     ks = {"k_ks_gemm<2,2> (int8 MFMA)": (40, {}), "k_keyswitch_fp<8,2,8>": (70, dict(ks_mfma=0)),
           "k_keyswitch_lanes<8,2,8>": (70, dict(ks_mfma=0, ks_fp=0)), "k_keyswitch_lanes<8,1,4>": (40, dict(ks_mfma=0)),
           "k_keyswitch<8>": (9, dict(ks_mfma=0))}

@@ -73,3 +73,41 @@ def test_lane_exchange_is_a_conflict_free_permutation():
                 assert len({w % 32 for w in words[32 * g:32 * g + 32]}) == 32, (layout.__name__, m, "read")
             for g in range(4):                # written 16 lanes at a time over 16
                 assert len({w % 16 for w in words[16 * g:16 * g + 16]}) == 16, (layout.__name__, m, "write")
+
+
+# ---- ... and of the 512-point one (LaneNtt512) -------------------------------------------------------------------------
+def lane512_phys(j):
+    return j ^ ((j >> 5) & 15) ^ (((j >> 4) & 1) << 3) ^ (((j >> 7) & 1) << 4)
+
+
+def lane512_index_b(ln, m):
+    return ((ln >> 4) << 7) | ((m & 1) << 6) | ((m >> 2) << 5) | (((m >> 1) & 1) << 4) | (ln & 15)
+
+
+def lane512_index_c(ln, m):
+    return ((ln & 31) << 4) | (m << 1) | (ln >> 5)
+
+
+def test_lane512_header_uses_these_formulas():
+    text = open(os.path.join(ROOT, "tfhe_fbs_map_amd", "csrc", "fbs_ntt_lane.hpp")).read()
+    assert "return j ^ ((j >> 5) & 15u) ^ (((j >> 4) & 1u) << 3) ^ (((j >> 7) & 1u) << 4);" in text
+    assert "return ((ln >> 4) << 7) | ((uint32_t)(m & 1) << 6) | ((uint32_t)(m >> 2) << 5) | ((uint32_t)((m >> 1) & 1) << 4) | (ln & 15u);" in text
+    assert "return ((ln & 31u) << 4) | ((uint32_t)m << 1) | (ln >> 5);" in text
+
+
+def test_lane512_exchange_is_a_conflict_free_permutation():
+    assert sorted(lane512_phys(j) for j in range(512)) == list(range(512))
+    for a in (1, 8, 64, 77, 300, 511):
+        for b in (2, 16, 128, 255, 448):
+            assert lane512_phys(a ^ b) == lane512_phys(a) ^ lane512_phys(b)
+    for layout in (lane512_index_b, lane512_index_c):
+        assert sorted(layout(ln, m) for ln in range(64) for m in range(8)) == list(range(512))
+        for ln in (0, 5, 37, 63):                                        # the kernel adds lane and register parts with XOR
+            for m in range(8):
+                assert layout(ln, m) == layout(ln, 0) ^ layout(0, m)
+        for m in range(8):
+            words = [lane512_phys(layout(ln, m)) for ln in range(64)]
+            for g in range(2):
+                assert len({w % 32 for w in words[32 * g:32 * g + 32]}) == 32, (layout.__name__, m, "read")
+            for g in range(4):
+                assert len({w % 16 for w in words[16 * g:16 * g + 16]}) == 16, (layout.__name__, m, "write")

@@ -552,12 +552,15 @@ static int upload_keys_t(fbs_ctx *ctx) {
         e = hipGetLastError();
         constexpr int LLS = lanes_log2_for_small_launch(LOGN);
         if constexpr (LLS != LL) {
-            if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL((k_bsk_transform<LOGN, LLS>), dim3(grid), dim3(1 << LLS), 0, ctx->stream, d_src,
-                                   reinterpret_cast<double *>(ctx->d_bsk_hat_small), reinterpret_cast<const double *>(ctx->d_tw_fwd),
-                                   n_inv, polys);
-                e = hipGetLastError();
+            // (two key bits per step run the main shape only: no second copy of a key that is 1.5 times the size)
+            if (ctx->group == 1) {
+                if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
+                if (e == hipSuccess) {
+                    hipLaunchKernelGGL((k_bsk_transform<LOGN, LLS>), dim3(grid), dim3(1 << LLS), 0, ctx->stream, d_src,
+                                       reinterpret_cast<double *>(ctx->d_bsk_hat_small), reinterpret_cast<const double *>(ctx->d_tw_fwd),
+                                       n_inv, polys);
+                    e = hipGetLastError();
+                }
             }
         }
     }

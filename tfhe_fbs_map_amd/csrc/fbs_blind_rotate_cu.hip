@@ -31,27 +31,78 @@ namespace fbs {
 #ifndef FBS_CU_WAVES_PER_EU
 #define FBS_CU_WAVES_PER_EU 2   // waves per SIMD the compiler must leave room for (4: two workgroups per CU, at most 128 registers per thread)
 #endif
+// The twiddles a wave needs for its part, both directions, and the two calls the kernel makes with them.  Every transform a
+// lane ever runs uses the same ones.  256-point parts (N = 1024): 9 + 9 per-lane doubles, all in registers.  512-point parts
+// (N = 2048): 17 + 17 -- the forward ones stay in registers, the inverse ones are read once per step from a [part][k][lane]
+// table the workgroup builds in LDS (64 consecutive words per read).
+template <class Part>
+struct CuTwiddles;
+template <>
+struct CuTwiddles<LaneNtt256> {
+    static constexpr int LDS_WORDS = 0;
+    LaneNtt256::Tw f, i;
+    // big_*: the table of the whole polynomial (wave-uniform reads at the part's root 4 + w); tw_*: the four parts' own tables
+    __device__ __forceinline__ void init(uniform_doubles big_f, uniform_doubles big_i, const double *tw_fwd, const double *tw_inv, uint32_t w,
+                                         uint32_t ln, double *) {
+        f = LaneNtt256::load(tw_fwd + w * 256u, big_f, 4u + w, ln);
+        i = LaneNtt256::load(tw_inv + w * 256u, big_i, 4u + w, ln);
+    }
+    template <int NL>
+    __device__ __forceinline__ void forward(double (&x)[NL][4], double *const (&bufs)[NL], uint32_t ln) const {
+        LaneNtt256::forward_multi<NL, 0>(x, bufs, ln, f, LaneNtt256::NoHook{});
+    }
+    __device__ __forceinline__ void inverse(double (&x)[4], double *buf, uint32_t ln) const { LaneNtt256::inverse_one(x, buf, ln, i); }
+};
+template <>
+struct CuTwiddles<LaneNtt512> {
+    static constexpr int LDS_WORDS = 4 * LaneNtt512::LANE_TW * 64;
+    LaneNtt512::Uniform uf, ui;
+    LaneNtt512::TwLane f;
+    const double *inv_table;
+    __device__ __forceinline__ void init(uniform_doubles big_f, uniform_doubles big_i, const double *tw_fwd, const double *tw_inv, uint32_t w,
+                                         uint32_t ln, double *lds) {
+        uf = LaneNtt512::load_uniform(big_f, 4u + w);
+        ui = LaneNtt512::load_uniform(big_i, 4u + w);
+        f = LaneNtt512::load_lane(tw_fwd + w * 512u, ln);
+        for (uint32_t e = threadIdx.x; e < (uint32_t)LDS_WORDS; e += blockDim.x) {   // (made visible by the barrier that follows)
+            const uint32_t part = e / (LaneNtt512::LANE_TW * 64u), k = e / 64u % LaneNtt512::LANE_TW, lane = e & 63u;
+            uint32_t node = 0;
+#pragma unroll
+            for (int kk = 0; kk < LaneNtt512::LANE_TW; kk++)
+                if ((uint32_t)kk == k) node = LaneNtt512::lane_node(lane, kk);
+            lds[e] = tw_inv[part * 512u + node];
+        }
+        inv_table = lds + w * (LaneNtt512::LANE_TW * 64u);
+    }
+    template <int NL>
+    __device__ __forceinline__ void forward(double (&x)[NL][8], double *const (&bufs)[NL], uint32_t ln) const {
+        LaneNtt512::forward_multi<NL, 0>(x, bufs, ln, uf, f, LaneNtt512::NoHook{});
+    }
+    __device__ __forceinline__ void inverse(double (&x)[8], double *buf, uint32_t ln) const {
+        LaneNtt512::inverse_one(x, buf, ln, ui, LaneNtt512::load_lane_table(inv_table, ln));
+    }
+};
+
 template <int LOGN, int NL, int FIRST>
 __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(BrArgs a) {
     using W = WavesNtt<LOGN, 2>;
     using Part = typename W::Half;
-    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M;
-    static_assert(LANES == 256 && E >= 4 && W::EP * 4 == E, "four waves per polynomial");
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M, EP = W::EP, LOGE = W::LOGE;
+    static_assert(LANES == 256 && (E == 4 || E == 8) && EP * 4 == E, "four waves per polynomial, 4 or 8 coefficients per lane");
     // LDS (doubles): [2][N] accumulator as the next rotation reads it (the hand-over borrows it between two rotations);
-    // [2][NL][N] re-deal + private exchange buffers of the forward transforms (level 0's doubles for the inverse).
-    // 64 KB at N = 1024, NL = 3.
-    __shared__ double lds_all[2 * N + 2 * NL * N];
+    // [2][NL][N] re-deal + private exchange buffers of the forward transforms (level 0's doubles for the inverse); the
+    // inverse per-lane twiddles of 512-point parts.  64 KB at N = 1024, NL = 3; 130 KB at N = 2048, NL = 2.
+    __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part>::LDS_WORDS];
     const uint32_t comp = threadIdx.x >> 8;          // GLWE component owned by this thread: 0 = mask, 1 = body
     const uint32_t t = threadIdx.x & (LANES - 1);    // thread of the component
     const uint32_t w = W::wave_of(t), ln = t & 63u;  // which part this wave owns; lane
     double *accbuf = lds_all + comp * N;
     double *accbuf_partner = lds_all + (comp ^ 1u) * N;
     double *xbuf = lds_all + 2 * N + comp * (NL * N);
-    // twiddles: every transform this lane ever runs uses the same ones -- loaded once (the per-lane ones from the part's own
-    // table, the wave-uniform ones from the big tree at the part's root 4 + w)
+    // twiddles: the per-lane ones from the part's own table, the wave-uniform ones from the big tree at the part's root 4 + w
     const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
-    const typename Part::Tw twf = Part::load(a.tw_fwd + W::LANE_TABLE_OFFSET + w * M, big_f, 4u + w, ln);
-    const typename Part::Tw twi = Part::load(a.tw_inv + W::LANE_TABLE_OFFSET + w * M, big_i, 4u + w, ln);
+    CuTwiddles<Part> tw;
+    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 2 * N + 2 * NL * N);
 
     const bool live = (size_t)blockIdx.x < a.count;
     const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
@@ -84,10 +135,8 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
         round_offset += (double)(bhalf << (j * a.beta));
         sign_bits |= bhalf << (j * a.beta);
     }
-    // cross-stage twiddles (wave-uniform, scalar registers for the whole rotation)
-    const double cw0 = big_f[1], cw1a = big_f[2], cw1b = big_f[3];
-    const double iw0 = big_i[1], iw1a = big_i[2], iw1b = big_i[3];
-    static_assert(E == 4, "the cross stages below are written out for four coefficients per thread");
+    // cross-stage twiddles: nodes 1, 2, 3 of the big tree (wave-uniform, scalar registers for the whole rotation)
+    const double cw[3] = {big_f[1], big_f[2], big_f[3]}, iw[3] = {big_i[1], big_i[2], big_i[3]};
 
 #pragma unroll
     for (int m = 0; m < E; m++) accbuf[t + (uint32_t)LANES * m] = acc[m];
@@ -135,21 +184,21 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
             const uint32_t shift = ((uint32_t)NL - 1u - (uint32_t)lv) * a.beta;
 #pragma unroll
             for (int m = 0; m < E; m++) x[lv][m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);
-            first_butterfly<FIRST>(x[lv][0], x[lv][2], cw0);
-            first_butterfly<FIRST>(x[lv][1], x[lv][3], cw0);
-            {
-                const double u = x[lv][0], v = fp_mulmod(x[lv][1], cw1a);
-                x[lv][0] = u + v;
-                x[lv][1] = u - v;
-            }
-            {
-                const double u = x[lv][2], v = fp_mulmod(x[lv][3], cw1b);
-                x[lv][2] = u + v;
-                x[lv][3] = u - v;
-            }
-            double *region = xbuf + lv * N;
+            // stage 0 pairs register m with m + E/2 (node 1), stage 1 m with m + E/4 inside each half (nodes 2, 3)
 #pragma unroll
-            for (int q = 0; q < 4; q++) region[q * M + t] = x[lv][q];
+            for (int m = 0; m < E / 2; m++) first_butterfly<FIRST>(x[lv][m], x[lv][m + E / 2], cw[0]);
+#pragma unroll
+            for (int m = 0; m < E; m++) {
+                if (m & (E / 4)) continue;
+                const double u = x[lv][m], v = fp_mulmod(x[lv][m + E / 4], cw[1 + (m >> (LOGE - 1))]);
+                x[lv][m] = u + v;
+                x[lv][m + E / 4] = u - v;
+            }
+            double *region = xbuf + lv * N;   // register q EP + r = element t + 256 r of part q
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int r = 0; r < EP; r++) region[q * M + t + (uint32_t)LANES * r] = x[lv][q * EP + r];
         }
         __syncthreads();
         double *bufs[NL];
@@ -159,7 +208,7 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 #pragma unroll
             for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
         }
-        Part::template forward_multi<NL, 0>(x, bufs, ln, twf, typename Part::NoHook{});
+        tw.template forward<NL>(x, bufs, ln);
 
         // ---- products with the key row: contributions to this component and to the partner's (lazy sums) ----------------
         double own[E], other[E];
@@ -183,32 +232,29 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 #pragma unroll
             for (int m = 0; m < E; m++) own[m] += accbuf[(uint32_t)LANES * m + t];
             // ---- private inverse, re-deal back -----------------------------------------------------------------------
-            Part::inverse_one(own, bufs[0], ln, twi);
+            tw.inverse(own, bufs[0], ln);
             Part::sync();
 #pragma unroll
             for (int m = 0; m < E; m++) bufs[0][ln + 64u * m] = own[m];
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 4; q++) own[q] = xbuf[q * M + t];
-        }
-        // ---- the two joining stages, accumulate -----------------------------------------------------------------------
-        {
-            {
-                const double u = own[0], v = own[1];
-                own[0] = u + v;
-                own[1] = fp_mulmod(u - v, iw1a);
-            }
-            {
-                const double u = own[2], v = own[3];
-                own[2] = u + v;
-                own[3] = fp_mulmod(u - v, iw1b);
-            }
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int m = 0; m < 2; m++) {
-                const double u = own[m], v = own[m + 2];
-                own[m] = u + v;
-                own[m + 2] = fp_mulmod(u - v, iw0);
-            }
+                for (int r = 0; r < EP; r++) own[q * EP + r] = xbuf[q * M + t + (uint32_t)LANES * r];
+        }
+        // ---- the two joining stages (Gentleman-Sande: nodes 2, 3, then node 1), accumulate ---------------------------------
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            if (m & (E / 4)) continue;
+            const double u = own[m], v = own[m + E / 4];
+            own[m] = u + v;
+            own[m + E / 4] = fp_mulmod(u - v, iw[1 + (m >> (LOGE - 1))]);
+        }
+#pragma unroll
+        for (int m = 0; m < E / 2; m++) {
+            const double u = own[m], v = own[m + E / 2];
+            own[m] = u + v;
+            own[m + E / 2] = fp_mulmod(u - v, iw[0]);
         }
 #pragma unroll
         for (int m = 0; m < E; m++) {
@@ -241,22 +287,26 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 
 bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
-    if (p.log_n_poly != 10 || ctx->group != 1 || !ctx->d_bsk_hat_small || p.l_bsk > 4) return false;
+    // N = 1024 with up to four gadget levels, N = 2048 with up to two (LDS: 2 N + 2 l N words + the inverse twiddles)
+    if (ctx->group != 1 || !ctx->d_bsk_hat_small) return false;
+    if (!((p.log_n_poly == 10 && p.l_bsk <= 4) || (p.log_n_poly == 11 && p.l_bsk <= 2))) return false;
     if (!ctx->tune.br_cu_kernel) return false;   // (A/B switch: the generic kernel on the four-wave transform)
     const int first = p.beta_bsk <= 7 ? 2 : p.beta_bsk <= 9 ? 1 : 0;
     BrArgs b = a;
     b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
     const dim3 grid((unsigned)a.count), block(512);
-#define CU_CASE(NL, FIRST)                                                                       \
-    if (p.l_bsk == NL && first == FIRST) {                                                       \
-        *kernel = "k_blind_rotate_cu<10," #NL "," #FIRST ">";                                    \
-        hipLaunchKernelGGL((k_blind_rotate_cu<10, NL, FIRST>), grid, block, 0, stream, b);       \
+#define CU_CASE(L, NL, FIRST)                                                                    \
+    if (p.log_n_poly == L && p.l_bsk == NL && first == FIRST) {                                  \
+        *kernel = "k_blind_rotate_cu<" #L "," #NL "," #FIRST ">";                                \
+        hipLaunchKernelGGL((k_blind_rotate_cu<L, NL, FIRST>), grid, block, 0, stream, b);        \
         return true;                                                                             \
     }
-    CU_CASE(1, 0) CU_CASE(1, 1) CU_CASE(1, 2)
-    CU_CASE(2, 0) CU_CASE(2, 1) CU_CASE(2, 2)
-    CU_CASE(3, 0) CU_CASE(3, 1) CU_CASE(3, 2)
-    CU_CASE(4, 2)   // (l * beta <= 30: four levels have at most 7 bits each)
+    CU_CASE(10, 1, 0) CU_CASE(10, 1, 1) CU_CASE(10, 1, 2)
+    CU_CASE(10, 2, 0) CU_CASE(10, 2, 1) CU_CASE(10, 2, 2)
+    CU_CASE(10, 3, 0) CU_CASE(10, 3, 1) CU_CASE(10, 3, 2)
+    CU_CASE(10, 4, 2)   // (l * beta <= 30: four levels have at most 7 bits each)
+    CU_CASE(11, 1, 0) CU_CASE(11, 1, 1) CU_CASE(11, 1, 2)
+    CU_CASE(11, 2, 0) CU_CASE(11, 2, 1) CU_CASE(11, 2, 2)
 #undef CU_CASE
     return false;
 }
@@ -265,6 +315,9 @@ void blind_rotate_cu_catalog(std::vector<std::string> *out) {
     for (int nl = 1; nl <= 4; nl++)
         for (int first = nl == 4 ? 2 : 0; first < 3; first++)
             out->push_back("k_blind_rotate_cu<10," + std::to_string(nl) + "," + std::to_string(first) + ">");
+    for (int nl = 1; nl <= 2; nl++)
+        for (int first = 0; first < 3; first++)
+            out->push_back("k_blind_rotate_cu<11," + std::to_string(nl) + "," + std::to_string(first) + ">");
 }
 
 }  // namespace fbs

@@ -362,12 +362,13 @@ struct PolyNtt {
 // per polynomial with 4 coefficients per lane (WavesNtt<10, 2>, fbs_ntt_split.hpp) -- one bootstrap is the eight waves a
 // CU holds of this kernel.  (Round 2: two waves per polynomial with 8 coefficients per lane, the generic PolyNtt<10, 7>
 // with two barriers per exchange: 4.8 ms per bootstrap.)  It needs its own transformed copy of the bootstrapping key (the
-// evaluation order differs).  Same as the main shape where there is no such alternative.
+// evaluation order differs).  N = 2048 likewise: four waves per polynomial with 8 coefficients per lane (WavesNtt<11, 2>) beside
+// the main shape's two waves with 16.  Same as the main shape where there is no such alternative.
 #ifndef FBS_SMALL_LAUNCH_LL_1024
 #define FBS_SMALL_LAUNCH_LL_1024 8
 #endif
 __host__ __device__ constexpr int lanes_log2_for_small_launch(int log_n) {
-    return log_n == 10 ? FBS_SMALL_LAUNCH_LL_1024 : (log_n <= 10 ? 6 : log_n - 4);
+    return log_n == 10 ? FBS_SMALL_LAUNCH_LL_1024 : log_n == 11 ? 8 : (log_n <= 10 ? 6 : log_n - 4);
 }
 
 #ifdef FBS_COEFS_PER_LANE_LOG2   // experiments: force 2^k coefficients per lane everywhere it is possible

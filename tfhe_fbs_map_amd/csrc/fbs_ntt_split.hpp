@@ -285,7 +285,8 @@ struct WavesNtt {
     // (N = 1024 on four waves: 256-point parts at 4 coefficients per lane, most of whose data movement is between registers and
     // lanes -- LaneNtt256, fbs_ntt_lane.hpp)
     using Half = typename std::conditional<E == 16, SplitNtt<(E == 16 ? LOGN - LOGW : 10), 6>,
-                                           typename std::conditional<E == 4 && M == 256, LaneNtt256, PolyNtt<LOGN - LOGW, 6>>::type>::type;
+                                           typename std::conditional<E == 4 && M == 256, LaneNtt256,
+                                                                     typename std::conditional<E == 8 && M == 512, LaneNtt512, PolyNtt<LOGN - LOGW, 6>>::type>::type>::type;
     static_assert((E == 16 || E == 8 || E == 4) && Half::E == E && E >= W && (LOGW == 1 || LOGW == 2), "two or four waves, 4, 8 or 16 coefficients per lane");
     // where the per-lane tables start inside the uploaded twiddle buffer: [N whole][N two halves][N four quarters]
     static constexpr int LANE_TABLE_OFFSET = LOGW * N;
@@ -418,7 +419,7 @@ using PairNtt = WavesNtt<LOGN, 1>;
 #ifndef FBS_PAIR_NTT
 #define FBS_PAIR_NTT 1   // experiments: 0 falls back to the generic two-wave transform for N = 2048
 #endif
-template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : (LL == 8 && (LOGN == 12 || LOGN == 10)) ? 3 : 0>
+template <int LOGN, int LL, int KIND = (LL == 6 && LOGN - LL == 4) ? 1 : (FBS_PAIR_NTT && LL == 7 && LOGN == 11) ? 2 : (LL == 8 && (LOGN == 12 || LOGN == 11 || LOGN == 10)) ? 3 : 0>
 struct NttFor {
     using type = PolyNtt<LOGN, LL>;
 };
