@@ -63,6 +63,8 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=["gate", "sample", "auto"], default="gate",
                     help="circuit: what is cut across the ranks (auto: distributed.choose_sharding lays them out)")
     ap.add_argument("--no-sharded-legs", action="store_true", help="batch, --gpus > 1: skip the gate- and sample-sharded circuit legs")
+    ap.add_argument("--sharded-circuit", default="trivium_stream_v2__search_p15", help="batch, --gpus > 1: the circuit of those legs")
+    ap.add_argument("--sharded-samples", type=int, default=64, help="... and its samples")
     ap.add_argument("--circuit", default="trivium_stream_v2__search_p15", help="circuit: fixture under tests/golden")
     ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
@@ -114,13 +116,20 @@ def worker(args):
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     have_gpu = torch.cuda.is_available()
     dist = None
+    # test hook (tests/test_gpu_bench.py): FBS_BENCH_SHARE_GPU=1 lets the ranks of a multi-rank run share the box's GPUs and meet
+    # over gloo -- RCCL refuses two ranks on one device -- so that the N > 1 code path of this file runs on a one-GPU box
+    share = have_gpu and os.environ.get("FBS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = local % torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        if have_gpu:
+        if have_gpu and not share:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group("gloo")         # a GPU-less host: the ranks still meet, then fail at the context
+            if have_gpu:
+                torch.cuda.set_device(local)
+            dist.init_process_group("gloo")         # (or a GPU-less host: the ranks still meet, then fail at the context)
     elif have_gpu:
         torch.cuda.set_device(local)
 
@@ -134,7 +143,7 @@ def worker(args):
             dist.destroy_process_group()
         return 3
     if args.workload == "batch" and world > 1 and not args.no_sharded_legs:
-        sharded = sharded_legs(rank, world, local, dist)              # every rank takes part; rank 0 holds the record
+        sharded = sharded_legs(rank, world, local, dist, args.sharded_circuit, args.sharded_samples)   # every rank takes part; rank 0 holds the record
         if rank == 0:
             result["sharded"] = sharded
     if rank == 0:
@@ -395,7 +404,7 @@ def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p1
         got = ctx.decrypt(out.cpu().numpy().view(np.uint64))
         ok = all(np.array_equal(got[k][:s1 - s0], clear[k][s0:s1]) for k, w in enumerate(low["out_wire"]) if w >= 0)
         legs[label] = dict(sample_groups=gs, gate_groups=world // gs, rccl_ranks=world, seconds=elapsed,
-                           value=prog.n_bootstrap * T / elapsed, unit="FBS/s", scaling="strong",
+                           value=prog.n_bootstrap * T / elapsed, unit="FBS/s", scaling="strong", backend=dist.get_backend(),
                            collectives_per_step=runner.collectives - before, allgather_ms_rank0=runner.collective_ms(),
                            kernels_ms_rank0={k: v["ms"] for k, v in prof.items()},
                            kernel_instantiations_rank0={k: dict(launches=v["launches"], ms=round(v["ms"], 3)) for k, v in kernels.items()},

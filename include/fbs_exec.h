@@ -109,7 +109,8 @@ int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows
  *   "ks_mfma" (1), "ks_fp" (1), "ks_cols_major" (1), "ks_split" (0 = automatic)   key-switch fallbacks / grid order
  *   "br_whole_cu" (1)       whole rounds of a launch as one four-bootstrap workgroup per CU
  *   "br_cu_kernel" (1)      launches that leave most of the chip empty as ONE bootstrap per CU (eight waves)
- *   "br_cu_max_per_cu" (2)  ... up to this many bootstraps per CU */
+ *   "br_cu_max_per_cu" (2)  ... up to this many bootstraps per CU
+ *   "br_cu_lean" (1)        ... and between one and two per CU as two 128-register workgroups per CU (2: always, 0: never) */
 int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value);
 /* counters: "scratch_growths" (how often a call (re)allocated scratch, i.e. blocked), "ms_capacity", "acc_capacity",
  * "wires_capacity", "next_nonce", "cu_count" */

@@ -63,3 +63,31 @@ def test_circuit_workload_at_the_secure_set():
                   "--steps", "1", "--warmup", "1", "--secure")
     assert d["decrypt_ok"] and d["config"]["params"]["security_bits_estimate"] >= 127.9
     assert "128-bit" in d["config"]["workload"]
+
+
+def test_two_rank_line_carries_the_sharded_legs():
+    """`bench.py --gpus 2` as the driver's torchrun starts it, on THIS box's one GPU (test hook FBS_BENCH_SHARE_GPU: the two ranks
+    share the device and meet over gloo, RCCL refusing two ranks on one device): the weak-scaling headline with its max-over-ranks
+    timing, and nested in the same line one circuit cut three ways with ranks, collectives per step, all-gather time, kernel
+    instantiations and a decrypt check per layout."""
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "128",
+           "--sharded-circuit", "adder8__search_p15", "--sharded-samples", "6"]
+    rc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, FBS_BENCH_SHARE_GPU="1"))
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    lines = [ln for ln in rc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["decrypt_ok"] and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 128 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # whole-job: both ranks' batches
+    legs = d["sharded"]["legs"]
+    assert {"gate", "sample"} <= set(legs)
+    for name, leg in legs.items():
+        assert leg["rccl_ranks"] == 2 and leg["decrypt_ok"] and leg["value"] > 0 and leg["scaling"] == "strong", name
+        assert leg["sample_groups"] * leg["gate_groups"] == 2
+        assert any("blind_rotate" in k for k in leg["kernel_instantiations_rank0"])
+    assert legs["gate"]["gate_groups"] == 2 and legs["gate"]["collectives_per_step"] > 0 and legs["gate"]["allgather_ms_rank0"] >= 0
+    assert legs["sample"]["collectives_per_step"] == 0 and legs["sample"]["allgather_ms_rank0"] == 0
+    assert d["sharded"]["choose_sharding"]["sample_groups"] * d["sharded"]["choose_sharding"]["gate_groups"] == 2

@@ -49,13 +49,15 @@ def recipe(name):
         L, dig = int(m.group(1)), int(m.group(3))
         l, beta = {4: (1, 20), 3: (2, 7), 0: (2, 10)}[dig]
         return dict(log_n=L, l=l, beta=beta, group=2, count=40, knobs={})
-    m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)>", name)
+    m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))
         beta = {2: 7, 1: 9, 0: 10}[first]
         if nl * beta > 30:
             beta = 30 // nl
-        return dict(log_n=L, l=nl, beta=beta, group=1, count=CUS + 3 if nl == 3 or (L, nl) == (11, 2) else 40, knobs={})
+        if m.group(4):                                    # two workgroups per CU: between one and two bootstraps per CU
+            return dict(log_n=L, l=nl, beta=beta, group=1, count=CUS + 70, knobs=dict(br_cu_lean=1))
+        return dict(log_n=L, l=nl, beta=beta, group=1, count=CUS + 3 if nl == 3 or (L, nl) == (11, 2) else 40, knobs=dict(br_cu_lean=0))
     ks = {"k_ks_gemm<2,2> (int8 MFMA)": (40, {}), "k_keyswitch_fp<8,2,8>": (70, dict(ks_mfma=0)),
           "k_keyswitch_lanes<8,2,8>": (70, dict(ks_mfma=0, ks_fp=0)), "k_keyswitch_lanes<8,1,4>": (40, dict(ks_mfma=0)),
           "k_keyswitch<8>": (9, dict(ks_mfma=0))}

@@ -35,26 +35,35 @@ namespace fbs {
 // lane ever runs uses the same ones.  256-point parts (N = 1024): 9 + 9 per-lane doubles, all in registers.  512-point parts
 // (N = 2048): 17 + 17 -- the forward ones stay in registers, the inverse ones are read once per step from a [part][k][lane]
 // table the workgroup builds in LDS (64 consecutive words per read).
-template <class Part>
+// LEAN (two workgroups per CU, 128 registers per thread): the inverse twiddles are not kept -- `prefetch_inverse` asks for them
+// (18 registers' worth, L1 / L2 hits) when the forward transforms are done, ahead of the products that cover their latency.
+template <class Part, bool LEAN>
 struct CuTwiddles;
-template <>
-struct CuTwiddles<LaneNtt256> {
+template <bool LEAN>
+struct CuTwiddles<LaneNtt256, LEAN> {
     static constexpr int LDS_WORDS = 0;
     LaneNtt256::Tw f, i;
+    const double *inv_part;
+    uniform_doubles inv_big;
+    uint32_t root, lane;
     // big_*: the table of the whole polynomial (wave-uniform reads at the part's root 4 + w); tw_*: the four parts' own tables
     __device__ __forceinline__ void init(uniform_doubles big_f, uniform_doubles big_i, const double *tw_fwd, const double *tw_inv, uint32_t w,
                                          uint32_t ln, double *) {
         f = LaneNtt256::load(tw_fwd + w * 256u, big_f, 4u + w, ln);
-        i = LaneNtt256::load(tw_inv + w * 256u, big_i, 4u + w, ln);
+        inv_part = tw_inv + w * 256u, inv_big = big_i, root = 4u + w, lane = ln;
+        if constexpr (!LEAN) i = LaneNtt256::load(inv_part, inv_big, root, lane);
     }
     template <int NL>
     __device__ __forceinline__ void forward(double (&x)[NL][4], double *const (&bufs)[NL], uint32_t ln) const {
         LaneNtt256::forward_multi<NL, 0>(x, bufs, ln, f, LaneNtt256::NoHook{});
     }
+    __device__ __forceinline__ void prefetch_inverse() {
+        if constexpr (LEAN) i = LaneNtt256::load(inv_part, inv_big, root, lane);
+    }
     __device__ __forceinline__ void inverse(double (&x)[4], double *buf, uint32_t ln) const { LaneNtt256::inverse_one(x, buf, ln, i); }
 };
-template <>
-struct CuTwiddles<LaneNtt512> {
+template <bool LEAN>
+struct CuTwiddles<LaneNtt512, LEAN> {
     static constexpr int LDS_WORDS = 4 * LaneNtt512::LANE_TW * 64;
     LaneNtt512::Uniform uf, ui;
     LaneNtt512::TwLane f;
@@ -78,13 +87,17 @@ struct CuTwiddles<LaneNtt512> {
     __device__ __forceinline__ void forward(double (&x)[NL][8], double *const (&bufs)[NL], uint32_t ln) const {
         LaneNtt512::forward_multi<NL, 0>(x, bufs, ln, uf, f, LaneNtt512::NoHook{});
     }
+    __device__ __forceinline__ void prefetch_inverse() {}
     __device__ __forceinline__ void inverse(double (&x)[8], double *buf, uint32_t ln) const {
         LaneNtt512::inverse_one(x, buf, ln, ui, LaneNtt512::load_lane_table(inv_table, ln));
     }
 };
 
-template <int LOGN, int NL, int FIRST>
-__global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(BrArgs a) {
+// LEAN: the variant for launches of between one and two bootstraps per CU -- 128 registers per thread, so that two workgroups
+// share a CU and fill each other's barrier and LDS stalls: the partner component's key words and the inverse twiddles are
+// requested after the forward transforms instead of being held through them.
+template <int LOGN, int NL, int FIRST, bool LEAN = false>
+__global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(BrArgs a) {
     using W = WavesNtt<LOGN, 2>;
     using Part = typename W::Half;
     constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M, EP = W::EP, LOGE = W::LOGE;
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
     // LDS (doubles): [2][N] accumulator as the next rotation reads it (the hand-over borrows it between two rotations);
     // [2][NL][N] re-deal + private exchange buffers of the forward transforms (level 0's doubles for the inverse); the
     // inverse per-lane twiddles of 512-point parts.  64 KB at N = 1024, NL = 3; 130 KB at N = 2048, NL = 2.
-    __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part>::LDS_WORDS];
+    __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part, LEAN>::LDS_WORDS];
     const uint32_t comp = threadIdx.x >> 8;          // GLWE component owned by this thread: 0 = mask, 1 = body
     const uint32_t t = threadIdx.x & (LANES - 1);    // thread of the component
     const uint32_t w = W::wave_of(t), ln = t & 63u;  // which part this wave owns; lane
@@ -101,7 +114,7 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
     double *xbuf = lds_all + 2 * N + comp * (NL * N);
     // twiddles: the per-lane ones from the part's own table, the wave-uniform ones from the big tree at the part's root 4 + w
     const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
-    CuTwiddles<Part> tw;
+    CuTwiddles<Part, LEAN> tw;
     tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 2 * N + 2 * NL * N);
 
     const bool live = (size_t)blockIdx.x < a.count;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
                 ko[lv][j] = k_own[j * LANES + t];
-                kt[lv][j] = k_oth[j * LANES + t];
+                if constexpr (!LEAN) kt[lv][j] = k_oth[j * LANES + t];
             }
         }
 
@@ -209,6 +222,16 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
             for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
         }
         tw.template forward<NL>(x, bufs, ln);
+        if constexpr (LEAN) {   // what the forward transforms had no registers for
+#pragma unroll
+            for (int lv = 0; lv < NL; lv++) {
+                const double *krow = a.bsk_hat + (((size_t)i * rows + comp * NL + lv) * 2) * N;
+                const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+#pragma unroll
+                for (int j = 0; j < E / 2; j++) kt[lv][j] = k_oth[j * LANES + t];
+            }
+            tw.prefetch_inverse();
+        }
 
         // ---- products with the key row: contributions to this component and to the partner's (lazy sums) ----------------
         double own[E], other[E];
@@ -217,9 +240,14 @@ __global__ __launch_bounds__(512, FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(Br
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
                 const double p0 = fp_mulmod(x[lv][2 * j], ko[lv][j].x), p1 = fp_mulmod(x[lv][2 * j + 1], ko[lv][j].y);
-                const double q0 = fp_mulmod(x[lv][2 * j], kt[lv][j].x), q1 = fp_mulmod(x[lv][2 * j + 1], kt[lv][j].y);
                 own[2 * j] = lv ? own[2 * j] + p0 : p0;
                 own[2 * j + 1] = lv ? own[2 * j + 1] + p1 : p1;
+            }
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++)
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) {
+                const double q0 = fp_mulmod(x[lv][2 * j], kt[lv][j].x), q1 = fp_mulmod(x[lv][2 * j + 1], kt[lv][j].y);
                 other[2 * j] = lv ? other[2 * j] + q0 : q0;
                 other[2 * j + 1] = lv ? other[2 * j + 1] + q1 : q1;
             }
@@ -295,8 +323,20 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
     BrArgs b = a;
     b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
     const dim3 grid((unsigned)a.count), block(512);
+    // more than one bootstrap per CU: the two-workgroups-per-CU variant where there is one (N = 1024, up to three levels)
+    // (512 bootstraps at P1024: 6.07 ms as two rounds of the 162-register kernel, 5.40 ms with two workgroups per CU; 1 536 =
+    // 1 024 + 512: 99.7 -> 105.3 k FBS/s)
+    const bool lean = p.log_n_poly == 10 && p.l_bsk <= 3 &&
+                      (ctx->tune.br_cu_lean == 2 || (ctx->tune.br_cu_lean == 1 && a.count > (size_t)ctx->cu_count));
 #define CU_CASE(L, NL, FIRST)                                                                    \
     if (p.log_n_poly == L && p.l_bsk == NL && first == FIRST) {                                  \
+        if constexpr (L == 10 && NL <= 3) {                                                      \
+            if (lean) {                                                                          \
+                *kernel = "k_blind_rotate_cu<" #L "," #NL "," #FIRST ",lean>";                   \
+                hipLaunchKernelGGL((k_blind_rotate_cu<L, NL, FIRST, true>), grid, block, 0, stream, b); \
+                return true;                                                                     \
+            }                                                                                    \
+        }                                                                                        \
         *kernel = "k_blind_rotate_cu<" #L "," #NL "," #FIRST ">";                                \
         hipLaunchKernelGGL((k_blind_rotate_cu<L, NL, FIRST>), grid, block, 0, stream, b);        \
         return true;                                                                             \
@@ -313,8 +353,10 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
 
 void blind_rotate_cu_catalog(std::vector<std::string> *out) {
     for (int nl = 1; nl <= 4; nl++)
-        for (int first = nl == 4 ? 2 : 0; first < 3; first++)
+        for (int first = nl == 4 ? 2 : 0; first < 3; first++) {
             out->push_back("k_blind_rotate_cu<10," + std::to_string(nl) + "," + std::to_string(first) + ">");
+            if (nl <= 3) out->push_back("k_blind_rotate_cu<10," + std::to_string(nl) + "," + std::to_string(first) + ",lean>");
+        }
     for (int nl = 1; nl <= 2; nl++)
         for (int first = 0; first < 3; first++)
             out->push_back("k_blind_rotate_cu<11," + std::to_string(nl) + "," + std::to_string(first) + ">");

@@ -206,6 +206,7 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     ctx->tune.br_whole_cu = getenv("FBS_BR_SMALL_WORKGROUPS") ? 0 : 1;
     ctx->tune.br_cu_kernel = getenv("FBS_BR_NO_CU_KERNEL") ? 0 : 1;
     ctx->tune.br_cu_max_per_cu = env_knob("FBS_BR_CU_MAX_PER_CU", ctx->tune.br_cu_max_per_cu);
+    ctx->tune.br_cu_lean = env_knob("FBS_BR_CU_LEAN", ctx->tune.br_cu_lean);
     const fbs_params &p = ctx->p;
     if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
         p.t_ksk > 64)
@@ -270,7 +271,7 @@ int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) {
     Tune &t = ctx->tune;
     int64_t *slot = k == "ks_gemm_min" ? &t.ks_gemm_min : k == "ks_mfma" ? &t.ks_mfma : k == "ks_fp" ? &t.ks_fp :
                     k == "ks_cols_major" ? &t.ks_cols_major : k == "ks_split" ? &t.ks_split : k == "br_whole_cu" ? &t.br_whole_cu :
-                    k == "br_cu_kernel" ? &t.br_cu_kernel : k == "br_cu_max_per_cu" ? &t.br_cu_max_per_cu : nullptr;
+                    k == "br_cu_kernel" ? &t.br_cu_kernel : k == "br_cu_max_per_cu" ? &t.br_cu_max_per_cu : k == "br_cu_lean" ? &t.br_cu_lean : nullptr;
     if (!slot) return set_error(ctx, FBS_E_INVALID, "unknown knob '" + k + "'");
     if (value < 0) return set_error(ctx, FBS_E_INVALID, "knob values are non-negative");
     *slot = value;

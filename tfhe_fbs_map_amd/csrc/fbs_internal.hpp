@@ -40,6 +40,7 @@ struct Tune {
     int64_t br_whole_cu = 1;        // 0: no whole-CU workgroups (four bootstraps per workgroup) in the blind rotation
     int64_t br_cu_kernel = 1;       // 0: no one-bootstrap-per-CU kernel (the generic kernel on the four-wave transform instead)
     int64_t br_cu_max_per_cu = 2;   // bootstraps per CU up to which a launch takes the one-bootstrap-per-CU kernel
+    int64_t br_cu_lean = 1;         // 1: between one and two per CU, its 128-register variant (two workgroups per CU); 2: always; 0: never
 };
 
 // ---- launch descriptors ------------------------------------------------------------------------

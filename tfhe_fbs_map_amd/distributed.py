@@ -160,9 +160,10 @@ def _all_gather_rows(out, send, world, group):
 # how to cut a program over G ranks
 # --------------------------------------------------------------------------------------------
 # One key switch + blind rotation launch of `count` bootstraps on one MI355X at the benchmark shape P1024, in ms
-# (profiles/r03/batch_sweep.txt).  Up to two bootstraps per CU a launch costs the latency of one or two bootstraps on a whole
-# CU (k_blind_rotate_cu), then the small workgroups, then whole rounds of four per CU; beyond a round, rounds + remainder.
-LAUNCH_MS_P1024 = ((1, 2.93), (128, 2.99), (256, 3.24), (257, 5.95), (512, 6.00), (513, 8.20), (768, 8.37), (769, 9.30), (1024, 9.50))
+# (profiles/r03/batch_sweep.txt).  Up to one bootstrap per CU a launch costs the latency of one bootstrap on a whole CU
+# (k_blind_rotate_cu), up to two that of two workgroups sharing a CU, then the small workgroups, then whole rounds of four per
+# CU; beyond a round, rounds + remainder.
+LAUNCH_MS_P1024 = ((1, 2.93), (128, 2.99), (256, 3.24), (257, 5.60), (512, 5.56), (513, 8.20), (768, 8.37), (769, 9.30), (1024, 9.50))
 ROUND_MS_P1024 = 9.30      # per further round of 1024 in a long launch (8192 bootstraps: 73.2 ms)
 
 
