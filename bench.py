@@ -354,8 +354,14 @@ def run_batch(args, rank, world, local, dist):
         result["cpu_baseline"] = cpu_baseline(prm, tables, cts, ids, out, args.cpu_sample)
     ctx.close()
     if world == 1 and not args.no_secure:
-        result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
+        sec = result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
         result["shared_rotations"] = shared_rotations_leg(local)
+        # (the headline shape is BASELINE's benchmark set at reduced noise; what a deployment runs, in one line of `config`)
+        p4 = sec["n1024_p4"]
+        result["config"]["secure_summary"] = (
+            "128-bit parameter sets, same batch: p=15 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step); p=4 at N=1024 %.0f FBS/s (n=%d l=%d)"
+            % (sec["value"], sec["params"]["n"], sec["params"]["N"], sec["params"]["l"], sec["params"]["key_bits_per_step"],
+               p4["value"], p4["params"]["n"], p4["params"]["l"]))
     return result
 
 

@@ -210,8 +210,12 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset
  * accumulator by a product with the small integer polynomial D_F (TV_F = TV_0 * D_F; multi-value bootstrap, Carpov,
  * Izabachene, Mollimard, CT-RSA 2019) and a sample extraction.  Same decrypted results; such an output carries more noise
  * than an ordinary bootstrap's (fbs_table_fusion_norms: the caller's parameter choice must carry it), and the ciphertexts
- * differ from the unfused program's.  Levels of a fused program run whole (fbs_eval,
- * fbs_eval_dev, fbs_level_bootstrap_dev over the full range without d_rows); slicing one across GPUs is refused. */
+ * differ from the unfused program's.  Into the wire slots a level of a fused program runs whole (fbs_eval, fbs_eval_dev,
+ * fbs_level_bootstrap_dev over the full range without d_rows).  Across GPUs the unit dealt out is the ROTATION:
+ * fbs_level_bootstrap_dev with d_rows takes any slice of the level's (rotation, sample) grid, its rows are
+ * fbs_layout.row_words = 2N words -- an ordinary gate leaves its ciphertext there, a shared rotation its whole accumulator --
+ * and fbs_level_scatter_dev, given all rows of the level, files the ciphertexts and cuts every table out of the gathered
+ * accumulators. */
 #define FBS_LOAD_FUSE_TABLES 1u
 int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset *tv, uint32_t flags, fbs_prog **out);
 /* What sharing a rotation does to the noise of table `table`'s output, with TV_F = Delta/2 G_F(X) (G_j = +-(2 f - c)):
@@ -243,7 +247,7 @@ int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, u
  *        level's [n_gates][s_count] grid (gate-major), each preceded by the key switch of its
  *        source -- one key switch per distinct (source wire, sample), shared by the gates that
  *        read it.  d_rows == NULL: results go to their wire slots; else to row f - f_begin of
- *        d_rows ([f_end - f_begin][D+1], e.g. the send buffer of an all-gather), and
+ *        d_rows ([f_end - f_begin][fbs_layout.row_words], e.g. the send buffer of an all-gather), and
  *   fbs_level_scatter_dev copies rows of such an array (after the all-gather) into the slots.
  * Samples [s_begin, s_begin + s_count) of every wire are processed; T is the sample stride. */
 typedef struct fbs_layout {
@@ -255,7 +259,7 @@ typedef struct fbs_layout {
     uint32_t n_keyswitch;  /* key switches in the program (<= n_bootstrap: shared sources)     */
     uint32_t n_inputs, n_outputs;
     uint32_t n_rotations;  /* blind rotations per sample (< n_bootstrap when tables share them)       */
-    uint32_t reserved;
+    uint32_t row_words;    /* words per row of the d_rows arrays below: D + 1, or 2N for a fused program       */
 } fbs_layout;
 int fbs_program_layout(const fbs_prog *prog, fbs_layout *out);
 int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources);

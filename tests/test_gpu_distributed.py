@@ -44,9 +44,10 @@ def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T):
 
 
 def test_two_ranks_on_a_fused_program(tmp_path):
-    """A program loaded with FBS_LOAD_FUSE_TABLES (several tables on one blind rotation): the sample-sharded layout works
-    unchanged and returns the single-process ciphertexts; cutting its levels across ranks is refused with an error that
-    says why (a shared rotation's tables are cut from one accumulator)."""
+    """A program loaded with FBS_LOAD_FUSE_TABLES (several tables on one blind rotation), cut across two ranks both ways.  Gate-
+    sharded, the unit dealt out is the ROTATION: rows are 2N words, a shared rotation's accumulator travels in its row, and every
+    rank cuts the tables out of the gathered accumulators.  Both layouts return the single-process (fused) ciphertexts, and rank 0
+    did about half of the rotations."""
     name, T = "adder8__basic_p2", 4
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")
@@ -59,12 +60,10 @@ def test_two_ranks_on_a_fused_program(tmp_path):
     rec = load_fixture(name)
     _, expect = subsample(rec, T)
     low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
-    assert int(z["gate_collectives"]) == -1 and int(z["sample_collectives"]) == 1
+    assert int(z["gate_collectives"]) == int(z["depth"]) and int(z["sample_collectives"]) == 1
     for k, w in enumerate(low["out_wire"]):
         if w >= 0:
+            assert np.array_equal(z["gate"][k], z["ref"][k])
             assert np.array_equal(z["sample"][k], z["ref"][k])
-            assert np.array_equal(ctx_free_decrypt(z, k), expect[low["out_names"][k]])
-
-
-def ctx_free_decrypt(z, k):
-    return z["dec_sample"][k]
+            assert np.array_equal(z["dec_sample"][k], expect[low["out_names"][k]])
+    assert int(z["gate_fbs"]) < int(z["n_bootstrap"]) * T * 0.6          # rotations, not tables: 22 of them for 37 tables

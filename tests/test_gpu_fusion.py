@@ -147,33 +147,42 @@ def test_tables_with_negative_values_below_the_facade(nat, toy_params):
         assert np.array_equal(ctx.decrypt(got[i]) % 14, np.array([full[x] for x in v]) % 14)
 
 
-def test_levels_of_a_fused_program_run_whole(nat, toy_params):
+def test_levels_of_a_fused_program_whole_or_sliced_into_rows(nat, toy_params):
+    """Into the wire slots a level with shared rotations runs whole (a partial range is refused).  Into ROWS it can be cut
+    anywhere: rows are `row_words` = 2N words, a shared rotation leaves its accumulator in its row, and the scatter call cuts
+    the tables out of the gathered rows -- same ciphertexts as the whole evaluation."""
     import torch
     rec = load_fixture("adder8__basic_p2")
     prm = params_for(toy_params, rec)
     T = 4
     ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
+    assert prog.row_words == 2 * prm.N
     ins, _ = subsample(rec, T)
     cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
     ref = prog.eval(cts, T)
     ctw = prm.ct_words
     wires = torch.zeros((prog.n_slots, T, ctw), dtype=torch.int64, device="cuda")
     wires[torch.from_numpy(prog.in_slot.astype(np.int64)).cuda()] = torch.from_numpy(cts.view(np.int64)).cuda()
-    sliced = 0
+    refused = 0
     for L in range(prog.depth + 1):
         prog.level_lincomb_dev(L, wires.data_ptr(), T, 0, T)
         if L == prog.depth:
             break
         total = prog.level_width[L] * T
-        try:                                                   # half a level: refused where tables share a rotation
-            rows = torch.empty((total // 2, ctw), dtype=torch.int64, device="cuda")
-            prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, 0, total // 2, d_rows=rows.data_ptr())
-        except nat.FbsError as e:
-            assert "cannot be sliced" in str(e)
-            sliced += 1
-        prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, 0, total)
+        if total > 1:
+            try:                                               # part of a level straight into the slots: refused where tables share a rotation
+                prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, 0, total // 2)
+            except nat.FbsError as e:
+                assert "runs whole" in str(e)
+                refused += 1
+        rows = torch.empty((total, prog.row_words), dtype=torch.int64, device="cuda")
+        cut = total // 3                                       # two unequal slices, as two ranks would compute them
+        for f0, f1 in ((0, cut), (cut, total)):
+            if f1 > f0:
+                prog.level_bootstrap_dev(L, wires.data_ptr(), T, 0, T, f0, f1, d_rows=rows[f0:].data_ptr())
+        prog.level_scatter_dev(L, wires.data_ptr(), T, 0, T, rows.data_ptr(), 0, total)
     ctx.sync()
-    assert sliced > 0
+    assert refused > 0
     got = wires.cpu().numpy().view(np.uint64)
     for k, slot in enumerate(prog.out_slot.tolist()):
         if slot >= 0:

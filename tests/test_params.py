@@ -113,3 +113,17 @@ def test_reduced_noise_search_and_error_probability():
     assert 5e-5 < p_error(4.0) < 7e-5 and p_error(6.0) < 3e-9              # "4 sigma" = 6.3e-5 (concrete.patch:56)
     v_br, v_ks, v_ms = variances(P1024)
     assert v_ms > v_ks > 0 and v_br > 0
+
+
+def test_exec_estimate_is_the_references_total_cost_in_this_executors_unit():
+    """experiments/add_exec_estimates.py + analyse_results.py: boot_cost(precision, sq_norm2) x nb_bootstrap.  Here boot_cost is
+    `bootstrap_cost` of the set the selector picks (P1024 = 1) and the time is that over the measured rate at cost 1."""
+    from tfhe_fbs_map_amd.params import MI355X_FBS_PER_S_AT_COST_1, bootstrap_cost, choose_params, exec_estimate
+    e = exec_estimate(15, 70, 482, samples=1000)
+    assert e["params"] == choose_params(15, 70) and e["boot_cost"] == bootstrap_cost(e["params"])
+    assert abs(e["total_cost"] - 482 * e["boot_cost"]) < 1e-9 and e["margin_sigmas"] >= 6.0
+    assert abs(e["seconds"] - e["total_cost"] * 1000 / MI355X_FBS_PER_S_AT_COST_1) < 1e-12
+    assert 3.0 < e["seconds"] < 7.0                              # the 16x16 multiplier on 1000 samples: 4.5 s measured at P1024
+    # more plaintext bits per bootstrap cost more per bootstrap (the reference's 40 / 47 / 69 / 75 points have the same order)
+    costs = [exec_estimate(p, 59, 1)["boot_cost"] for p in (4, 9, 17, 31)]
+    assert costs == sorted(costs)

@@ -36,7 +36,7 @@ class _Params(C.Structure):
 
 class _Layout(C.Structure):
     _fields_ = [(f, C.c_uint32) for f in ("n_slots", "n_levels", "max_width", "max_sources", "n_bootstrap", "n_keyswitch",
-                                          "n_inputs", "n_outputs", "n_rotations", "reserved")]
+                                          "n_inputs", "n_outputs", "n_rotations", "row_words")]
 
 
 class _ProgramDesc(C.Structure):
@@ -259,6 +259,7 @@ class Program:
         self.depth, self.max_width, self.n_bootstrap = lay.n_levels, lay.max_width, lay.n_bootstrap
         self.n_slots, self.n_keyswitch, self.max_sources = lay.n_slots, lay.n_keyswitch, lay.max_sources
         self.n_rotations = lay.n_rotations
+        self.row_words = lay.row_words          # words per row of the d_rows arrays of the level calls (2N for a fused program)
         self.in_slot = np.empty(self.n_inputs, np.uint32)
         self.out_slot = np.empty(self.n_outputs, np.int64)
         ctx._check(lib.fbs_program_io_slots(h, _ptr(self.in_slot), _ptr(self.out_slot)))

@@ -666,7 +666,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     a.beta = p.beta_bsk;
     a.ct_words = ctx->D + 1;
     // (entry n_tables of the set is TV_0: selectable only by the rotations of a fused program, whose ids the host wrote)
-    a.n_tables = gv.acc_rows ? tv->n_tables + 1 : std::max(1u, tv->n_tables);
+    a.n_tables = (gv.acc_rows || gv.row_words) ? tv->n_tables + 1 : std::max(1u, tv->n_tables);
     const size_t count = gv.count;
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "batch too large for one launch");
@@ -736,7 +736,7 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         GateView rest = gv;                       // what did not fill a round: its own launch, in the shape its size asks for
         rest.f_begin += whole;
         rest.count = count - whole;
-        if (rest.out_rows) rest.out_rows += whole * (size_t)(ctx->D + 1);
+        if (rest.out_rows) rest.out_rows += whole * (size_t)(rest.row_words ? rest.row_words : ctx->D + 1);
         return dev_blind_rotate(ctx, tv, rest, d_ms, stream);
     } else if (p.log_n_poly == 10 && (dig == 6 || dig == 7) && count > 8 * (size_t)ctx->cu_count) {
         // the two-level 128-bit sets at N = 1024 in launches of more than two rounds: no taking turns (see TURNS)

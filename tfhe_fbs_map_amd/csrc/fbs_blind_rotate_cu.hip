@@ -5,19 +5,21 @@
 // A bootstrap's latency is n CMUX steps one after the other; inside a step the work is (k+1) l forward transforms, their
 // products with the key row, and k+1 inverse transforms.  The two-waves-per-bootstrap kernel runs those one after the other in
 // each wave (3 535 FP64-pipe instructions per wave and step at P1024: 4.8 ms per bootstrap however empty the chip is).  Here
-// the N = 1024 coefficients of a GLWE component are dealt over FOUR waves (4 coefficients per lane; component c = waves 4c ..
-// 4c+3), as in WavesNtt<10, 2>:
-//   * the first two Cooley-Tukey stages pair registers of one thread and leave four independent 256-point transforms hanging
+// the N coefficients of a GLWE component are dealt over FOUR waves (N = 1024: 4 coefficients per lane, N = 2048: 8; component
+// c = waves 4c .. 4c+3), as in WavesNtt<LOGN, 2>:
+//   * the first two Cooley-Tukey stages pair registers of one thread and leave four independent N/4-point transforms hanging
 //     from nodes 4 .. 7 of the twiddle tree; ONE trip through LDS re-deals them so that wave w owns part w;
-//   * everything after that is private to a wave (PolyNtt<8, 6>: no workgroup barrier), and the l digit levels of a component
-//     go through it TOGETHER (fwd_from_multi): one re-deal, one twiddle fetch and one exchange per group for all levels, and
-//     2 l independent butterflies per stage to cover the FP64 pipe's latency where a single 4-coefficient transform has two;
+//   * everything after that is private to a wave: LaneNtt256 / LaneNtt512 (fbs_ntt_lane.hpp) move index bits between registers
+//     and lanes with v_permlane32/16_swap and go through LDS once per transform, and the l digit levels of a component go
+//     through it TOGETHER (forward_multi): one re-deal and one exchange for all levels, 2 l (4 l) independent butterflies per
+//     stage to cover the FP64 pipe's latency;
 //   * products with the key row, hand-over of the partner component's half, private inverse transform, one re-deal back, the
 //     two joining stages, accumulate.
 // Four workgroup barriers per step (re-deal, hand-over, re-deal back, accumulator published for the next rotation) against
 // twelve when the generic kernel is instantiated with the four-wave transform (4.15 ms) and twenty-eight with round 2's
-// two-wave transform (4.8 ms).  The key copy is the one k_blind_rotate<10, 8, ...> uses (d_bsk_hat_small: evaluation order of
-// WavesNtt<10, 2>).
+// two-wave transform (4.8 ms).  The key copy is the one k_blind_rotate<LOGN, 8, ...> uses (d_bsk_hat_small: evaluation order of
+// WavesNtt<LOGN, 2>).  Measured at P1024: 2.9 ms per bootstrap at up to 128, 3.15 ms at 256 bootstraps; the `lean` variant (two
+// 128-register workgroups per CU) 5.4 ms for 512.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

@@ -44,6 +44,8 @@ struct BootStage {
     // of the extraction list below (k_multi_extract)
     uint32_t n_shared = 0, n_extract = 0;
     uint32_t *d_x_row = nullptr, *d_x_table = nullptr, *d_x_dst = nullptr;   // [n_extract] shared index, table, wire slot
+    uint32_t *d_x_gate = nullptr;      // [n_extract] position of the shared rotation in the gate list (a level cut across GPUs
+                                       // finds the accumulator in that gate's gathered row)
 };
 struct fbs_prog {
     fbs_ctx *ctx = nullptr;
@@ -797,7 +799,7 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
         std::vector<Gate> &gates = bh[L];
         std::stable_sort(gates.begin(), gates.end(), [](const Gate &x, const Gate &y) { return x.src < y.src; });
         BootStage st;
-        std::vector<uint32_t> src_slot, dst, tab, x_row, x_table, x_dst;
+        std::vector<uint32_t> src_slot, dst, tab, x_row, x_table, x_dst, x_gate;
         for (size_t g = 0; g < gates.size();) {
             size_t e = g;
             while (e < gates.size() && gates[e].src == gates[g].src) e++;
@@ -809,6 +811,7 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
             if (prog->fused)
                 for (size_t i = g; i < e; i++) n_fusable += tv->fusable[gates[i].tab];
             const bool share = n_fusable >= 2;
+            const uint32_t shared_at = (uint32_t)dst.size();
             if (share) {
                 st.source_of.push_back(u);
                 dst.push_back(0x80000000u | st.n_shared);
@@ -817,6 +820,7 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
             for (size_t i = g; i < e; i++) {
                 if (share && tv->fusable[gates[i].tab]) {
                     x_row.push_back(st.n_shared);
+                    x_gate.push_back(shared_at);
                     x_table.push_back(gates[i].tab);
                     x_dst.push_back(gates[i].dst);
                 } else {
@@ -840,7 +844,7 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
             (rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), tab, &st.d_table)))
             return rc;
         if (st.n_extract && ((rc = to_device(ctx, prog.get(), x_row, &st.d_x_row)) || (rc = to_device(ctx, prog.get(), x_table, &st.d_x_table)) ||
-                             (rc = to_device(ctx, prog.get(), x_dst, &st.d_x_dst))))
+                             (rc = to_device(ctx, prog.get(), x_dst, &st.d_x_dst)) || (rc = to_device(ctx, prog.get(), x_gate, &st.d_x_gate))))
             return rc;
         prog->boot[L] = std::move(st);
     }
@@ -872,7 +876,7 @@ int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) {
     out->n_bootstrap = prog->n_bootstrap;
     out->n_keyswitch = prog->n_keyswitch;
     out->n_rotations = prog->n_rotations;
-    out->reserved = 0;
+    out->row_words = prog->fused ? 2 * prog->ctx->N : prog->ctx->D + 1;
     out->n_inputs = prog->n_inputs;
     out->n_outputs = prog->n_outputs;
     return FBS_OK;
@@ -923,10 +927,12 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     const BootStage &b = prog->boot[level];
     if (f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad bootstrap range");
     if (f_begin == f_end) return FBS_OK;   // (covers s_count == 0)
-    // a level with shared rotations runs whole: the tables of one source are cut from one accumulator, there is no row of
-    // a contiguous array per bootstrap to hand out (load without FBS_LOAD_FUSE_TABLES to slice levels across GPUs)
-    if (b.n_shared && (d_rows || f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
-        return set_error(ctx, FBS_E_INVALID, "a level of a fused program cannot be sliced");
+    // A level with shared rotations: into the wire slots it runs whole (the tables of one source are cut from one accumulator
+    // right after the rotations).  Into rows it can be SLICED: rows are then 2N words (fbs_layout.row_words), an ordinary gate
+    // leaves its ciphertext in its row and a shared rotation its whole accumulator -- the unit dealt out across GPUs is the
+    // rotation -- and fbs_level_scatter_dev cuts the tables out once every row is there.
+    if (b.n_shared && !d_rows && (f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
+        return set_error(ctx, FBS_E_INVALID, "a level of a fused program runs whole when it writes to the wire slots (slice it into rows)");
     // the key switches this slice needs: the (source, sample) pairs of its gates, as ONE flattened range.  Gates are
     // sorted by source, so only the first and the last gate of the slice can be cut short in the sample direction, and
     // only while no other gate of the slice shares their source.
@@ -943,6 +949,7 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     gv.table_ids = b.d_table;
     gv.source_of = b.d_source_of;
     gv.out_rows = d_rows;
+    gv.row_words = (d_rows && prog->fused) ? 2 * ctx->N : 0;
     gv.T = T;
     gv.s_begin = s_begin;
     gv.s_count = s_count;
@@ -953,7 +960,7 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     gv.n_gates = b.n_gates;
     rc = ensure_ms(ctx, gv.ks_count);
     if (rc != FBS_OK) return rc;
-    if (b.n_shared) {
+    if (b.n_shared && !d_rows) {
         if ((rc = ensure_acc(ctx, (size_t)b.n_shared * s_count)) != FBS_OK) return rc;
         gv.acc_rows = ctx->d_acc;
     }
@@ -961,8 +968,8 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     if ((rc = scratch_wait(ctx, s)) != FBS_OK) return rc;
     if ((rc = dev_keyswitch(ctx, gv, ctx->d_ms, s)) != FBS_OK) return scratch_fail(ctx, s, rc);
     if ((rc = dev_blind_rotate(ctx, prog->tv, gv, ctx->d_ms, s)) != FBS_OK) return scratch_fail(ctx, s, rc);
-    if (b.n_shared && (rc = dev_multi_extract(ctx, prog->tv, ctx->d_acc, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_row, b.d_x_table,
-                                              b.d_x_dst, s)) != FBS_OK)
+    if (b.n_shared && !d_rows &&
+        (rc = dev_multi_extract(ctx, prog->tv, ctx->d_acc, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_row, b.d_x_table, b.d_x_dst, s)) != FBS_OK)
         return scratch_fail(ctx, s, rc);
     return scratch_done(ctx, s);
 }
@@ -974,8 +981,14 @@ int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
     if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
     const BootStage &b = prog->boot[level];
     if (!d_rows || f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad row range");
-    if (b.n_shared) return set_error(ctx, FBS_E_INVALID, "a level of a fused program cannot be sliced");
-    return dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, pick(ctx, stream));
+    if (!prog->fused) return dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, 0, pick(ctx, stream));
+    // fused: rows of 2N words; the tables of shared rotations are cut out of the gathered accumulators, which takes every row
+    if (b.n_shared && (f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
+        return set_error(ctx, FBS_E_INVALID, "scattering a level of a fused program takes all of its rows");
+    rc = dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, 2 * ctx->N, pick(ctx, stream));
+    if (rc != FBS_OK || !b.n_shared) return rc;
+    return dev_multi_extract(ctx, prog->tv, d_rows, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_gate, b.d_x_table, b.d_x_dst,
+                             pick(ctx, stream));
 }
 
 static int run_levels(fbs_ctx *ctx, const fbs_prog *prog, uint64_t *d_wires, size_t T, size_t s_count, hipStream_t s) {

@@ -20,7 +20,7 @@ __device__ __forceinline__ void gate_of(const GateView &gv, size_t i, size_t *ga
     *ms_row = u * gv.s_count + s - gv.ks_begin;
 }
 __device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t i, uint32_t ct_words) {
-    if (gv.out_rows) return gv.out_rows + i * ct_words;
+    if (gv.out_rows) return gv.out_rows + i * (gv.row_words ? gv.row_words : ct_words);
     const size_t f = gv.f_begin + i;
     const size_t g = f / gv.s_count, s = gv.s_begin + f % gv.s_count;
     const size_t slot = gv.dst_slot ? gv.dst_slot[g] : g;
@@ -29,11 +29,13 @@ __device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t i, uint
 
 // fused programs: the scratch row a rotation of TV_0 leaves its whole accumulator in, or null for an ordinary gate
 __device__ __forceinline__ uint64_t *gate_acc(const GateView &gv, size_t i, uint32_t N) {
-    if (!gv.acc_rows) return nullptr;
+    const bool in_row = gv.out_rows && gv.row_words;   // a fused level cut across GPUs: the accumulator goes into the gate's row
+    if (!gv.acc_rows && !in_row) return nullptr;
     const size_t f = gv.f_begin + i;
     const size_t g = f / gv.s_count, s = f % gv.s_count;
     const uint32_t d = gv.dst_slot[g];
     if (!(d & 0x80000000u)) return nullptr;
+    if (in_row) return gv.out_rows + i * gv.row_words;
     return gv.acc_rows + ((size_t)(d & 0x7FFFFFFFu) * gv.s_count + s) * 2 * N;
 }
 

@@ -58,6 +58,8 @@ struct GateView {
     // emits several tables per linear combination): source_of[g] = index of gate g's source in src_slot, null = g.
     const uint32_t *source_of;  // [n_gates] or null
     uint64_t *out_rows;         // non-null: bootstrap f writes row (f - f_begin) of this contiguous array instead of its slot
+    uint32_t row_words;         // words per row of out_rows; 0 = one ciphertext (D + 1).  2N for a fused level cut across GPUs:
+                                // a shared rotation then leaves its whole accumulator in its row (it travels with the gather)
     // Several tables on ONE blind rotation (fused programs, fbs_program_load_ex): a gate whose dst_slot has bit 31 set is
     // the rotation of the table-independent test vector TV_0 for a source that several tables read; it leaves its whole
     // accumulator in row (dst & 0x7fffffff) * s_count + sample of acc_rows ([row][2][N]) for k_multi_extract.
@@ -198,8 +200,9 @@ int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_
                 const uint32_t *d_dst, const uint32_t *d_term_off, const uint32_t *d_srcs, const uint64_t *d_coefs,
                 const uint64_t *d_consts, hipStream_t stream);
 // rows[f - f_begin] -> wire slot dst_slot[f / s_count], sample s_begin + f % s_count, for f in [f_begin, f_begin + count)
+// (row_words = 0: rows are ciphertexts; else the row stride, and gates whose dst_slot has bit 31 set -- shared rotations -- are skipped)
 int dev_scatter_rows(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, const uint32_t *d_dst_slot,
-                     const uint64_t *d_rows, size_t f_begin, size_t count, hipStream_t stream);
+                     const uint64_t *d_rows, size_t f_begin, size_t count, uint32_t row_words, hipStream_t stream);
 // rows of `count` ciphertexts: out[i] = wires[slot][s_begin + i] (slot >= 0) or the trivial ciphertext of `body`
 int dev_copy_out(fbs_ctx *ctx, const uint64_t *d_wires, size_t T, size_t s_begin, size_t count, int64_t slot, uint64_t body,
                  uint64_t *d_out, hipStream_t stream);

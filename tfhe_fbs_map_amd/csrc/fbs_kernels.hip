@@ -576,11 +576,12 @@ __global__ __launch_bounds__(256) void k_lincomb(uint64_t *wires, size_t T, size
 // rows of a contiguous array -> wire slots (the gate-sharded multi-GPU mode publishes a level's bootstraps as one
 // contiguous all-gathered array; this puts them where the next level's linear combinations look for them)
 __global__ __launch_bounds__(256) void k_scatter_rows(uint64_t *wires, size_t T, size_t s_begin, size_t s_count, uint32_t ct_words,
-                                                      const uint32_t *dst_slot, const uint64_t *rows, size_t f_begin) {
+                                                      const uint32_t *dst_slot, const uint64_t *rows, size_t f_begin, uint32_t row_words) {
     const size_t f = f_begin + blockIdx.x;
     const size_t g = f / s_count, s = s_begin + f % s_count;
+    if (dst_slot[g] & 0x80000000u) return;   // a shared rotation's row holds an accumulator: k_multi_extract reads it
     uint64_t *out = wires + ((size_t)dst_slot[g] * T + s) * ct_words;
-    const uint64_t *in = rows + (size_t)blockIdx.x * ct_words;
+    const uint64_t *in = rows + (size_t)blockIdx.x * row_words;
     for (uint32_t j = threadIdx.x; j < ct_words; j += 256) out[j] = in[j];
 }
 
@@ -860,11 +861,11 @@ int dev_lincomb(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_
 }
 
 int dev_scatter_rows(fbs_ctx *ctx, uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count, const uint32_t *d_dst_slot,
-                     const uint64_t *d_rows, size_t f_begin, size_t count, hipStream_t stream) {
+                     const uint64_t *d_rows, size_t f_begin, size_t count, uint32_t row_words, hipStream_t stream) {
     if (count == 0) return FBS_OK;
     if (count > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "more than 2^31 rows in one launch");
     hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)count), dim3(256), 0, stream, d_wires, T, s_begin, s_count, ctx->D + 1, d_dst_slot,
-                       d_rows, f_begin);
+                       d_rows, f_begin, row_words ? row_words : ctx->D + 1);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;
 }

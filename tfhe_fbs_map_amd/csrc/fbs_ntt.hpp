@@ -225,90 +225,6 @@ struct PolyNtt {
         }
     }
 
-    // NP polynomials at once through the same transform (same twiddles, one exchange buffer each): one twiddle fetch and one
-    // trip through LDS per group serve all of them, and their butterflies interleave -- NP * E/2 independent products per
-    // stage where one polynomial at E = 4 has two.  Same arithmetic per polynomial as fwd_from (one-buffer exchanges).
-    template <int NP, int G, int FIRST>
-    __device__ static __forceinline__ void fwd_from_multi(double (&x)[NP][E], double *const (&bufs)[NP], uint32_t t, const Twiddles &tw,
-                                                          uint32_t R = 1) {
-        static_assert(LL <= FBS_ONE_BUFFER_MAX_LL, "one exchange buffer per polynomial");
-        constexpr int lo = lo_of(G);
-        constexpr int s_begin = G * LOGE;
-        constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
-        double w[LOGE + 1][E / 2];
-        load_stage<G>(s_begin, t, tw, w[0], R);
-#pragma unroll
-        for (int s = s_begin; s < s_end; s++) {
-            const int bit = LOGN - 1 - s - lo;
-            const int hm = 1 << bit;
-            if (s + 1 < s_end) load_stage<G>(s + 1, t, tw, w[s + 1 - s_begin], R);
-#pragma unroll
-            for (int m = 0; m < E; m++) {
-                if (m & hm) continue;
-                const double wv = w[s - s_begin][m >> (bit + 1)];
-#pragma unroll
-                for (int p = 0; p < NP; p++) {
-                    if (s == 0) {
-                        first_butterfly<FIRST>(x[p][m], x[p][m + hm], wv);
-                        continue;
-                    }
-                    const double u = x[p][m];
-                    const double v = fp_mulmod(x[p][m + hm], wv);
-                    x[p][m] = u + v;
-                    x[p][m + hm] = u - v;
-                }
-            }
-        }
-        if constexpr (G + 1 < GROUPS) {
-            sync();   // the stores stay behind the reads that filled x
-#pragma unroll
-            for (int p = 0; p < NP; p++) store_group<G>(bufs[p], t, x[p]);
-            sync();
-#pragma unroll
-            for (int p = 0; p < NP; p++) load_group<G + 1>(bufs[p], t, x[p]);
-            fwd_from_multi<NP, G + 1, FIRST>(x, bufs, t, tw, R);
-        }
-    }
-    template <int NP, int G>
-    __device__ static __forceinline__ void inv_from_multi(double (&x)[NP][E], double *const (&bufs)[NP], uint32_t t, const Twiddles &tw,
-                                                          uint32_t R = 1) {
-        static_assert(LL <= FBS_ONE_BUFFER_MAX_LL, "one exchange buffer per polynomial");
-        constexpr int lo = lo_of(G);
-        constexpr int s_begin = G * LOGE;
-        constexpr int s_end = (G + 1) * LOGE < LOGN ? (G + 1) * LOGE : LOGN;
-        double w[LOGE + 1][E / 2];
-        load_stage<G>(s_end - 1, t, tw, w[s_end - 1 - s_begin], R);
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-#pragma unroll
-            for (int m = 0; m < E; m++) x[p][m] = fp_center(x[p][m]);
-#pragma unroll
-        for (int s = s_end - 1; s >= s_begin; s--) {
-            const int bit = LOGN - 1 - s - lo;
-            const int hm = 1 << bit;
-            if (s > s_begin) load_stage<G>(s - 1, t, tw, w[s - 1 - s_begin], R);
-#pragma unroll
-            for (int m = 0; m < E; m++) {
-                if (m & hm) continue;
-#pragma unroll
-                for (int p = 0; p < NP; p++) {
-                    const double u = x[p][m], v = x[p][m + hm];
-                    x[p][m] = u + v;
-                    x[p][m + hm] = fp_mulmod(u - v, w[s - s_begin][m >> (bit + 1)]);
-                }
-            }
-        }
-        if constexpr (G > 0) {
-            sync();
-#pragma unroll
-            for (int p = 0; p < NP; p++) store_group<G>(bufs[p], t, x[p]);
-            sync();
-#pragma unroll
-            for (int p = 0; p < NP; p++) load_group<G - 1>(bufs[p], t, x[p]);
-            inv_from_multi<NP, G - 1>(x, bufs, t, tw, R);
-        }
-    }
-
     // coefficients (group-0 layout: register m of lane t = coefficient t + LANES*m, |x| <= q) -> evaluations
     // (last-group layout, |x| < 9.3 q)
     __device__ static __forceinline__ void forward(double (&x)[E], Xchg &xc, uint32_t t, const Twiddles &tw) {

@@ -220,3 +220,23 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
         raise ValueError("no parameter set with N <= %d reaches %.1f sigma at p = %d, norm2 = %g"
                          % (1 << max(poly_sizes), min_margin, p, norm2))
     return best[1]
+
+
+# ---- execution estimates: the reference's cost unit, in this executor's terms -------------------------------------------
+# One MI355X at the benchmark shape P1024 (cost 1.0) in whole rounds of 1 024 bootstraps: profiles/r03/batch_sweep.txt,
+# 106-110 k FBS/s by the box.  Everything `exec_estimate` says about time is this figure scaled by `bootstrap_cost`.
+MI355X_FBS_PER_S_AT_COST_1 = 107e3
+
+
+def exec_estimate(p: int, norm2: float, nb_bootstrap: int, samples: int = 1, **choose) -> dict:
+    """What the reference's flow computes for a mapped circuit with its patched optimizer (experiments/add_exec_estimates.py:9-16:
+    `boot_cost` of (precision = fbs_size, sq_norm2 = norm2_linprod); experiments/analyse_results.py: `total_cost = nb_bootstrap x
+    boot_cost`), restated for THIS executor: the parameter set `choose_params(p, norm2)` picks, its `bootstrap_cost` (issue slots of
+    these kernels, P1024 = 1) as `boot_cost`, `total_cost = nb_bootstrap x boot_cost`, and what that is in time on one MI355X when
+    the levels are wide enough to fill whole rounds (`seconds`; narrow levels pay one bootstrap's latency per level instead:
+    distributed.launch_ms prices those)."""
+    prm = choose_params(p, norm2, **choose)
+    cost = bootstrap_cost(prm)
+    total = nb_bootstrap * cost
+    return dict(params=prm, boot_cost=cost, total_cost=total, margin_sigmas=margin_sigmas(prm, norm2),
+                seconds=total * samples / MI355X_FBS_PER_S_AT_COST_1, samples=samples)
