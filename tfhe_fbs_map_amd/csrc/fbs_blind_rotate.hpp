@@ -54,6 +54,8 @@ __device__ __forceinline__ void lead_if(uint32_t turn, uint32_t slot) {
 // fbs_blind_rotate_cu.hip: one bootstrap on the eight waves of a CU (N = 1024, at most four gadget levels).  Returns false when
 // there is no instantiation for the context's parameters (the caller then takes the generic kernel); *kernel = its name.
 bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
+// ... with two key bits per step (N = 2048, one gadget level)
+bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_cu_catalog(std::vector<std::string> *out);
 
 }  // namespace fbs

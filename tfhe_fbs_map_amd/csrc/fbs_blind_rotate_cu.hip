@@ -315,6 +315,225 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same shape for TWO KEY BITS PER STEP (bsk_group = 2; k_blind_rotate_pairs in fbs_blind_rotate.hip has the algebra): what
+// the 128-bit parameter sets for p = 15 take (N = 2048, one gadget level, n/2 steps).  Per pair of key bits with rotation
+// amounts (a0, a1) and e = (a0, a1, a0 + a1):
+//     ACC += [ (X^e0 - 1) E0 + (X^e1 - 1) E1 + (X^e2 - 1) E2 ]  (x)  ACC,
+// the bundle built in the transform domain, where X^e - 1 is the pointwise factor zeta^e - 1 with zeta the evaluation point a
+// register holds.  ACC ITSELF is decomposed, so there is no rotated read and no barrier for one: three per step.
+//
+// Evaluation points in the LaneNtt512 layout.  Array position P = 512 w + j holds the value at psi^(2 bitrev11(P) + 1); after
+// forward_multi register m = (r2 r1 r0) of lane ln of wave w holds j = (ln & 31) << 4 | (ln >> 5) << 3 | r1 << 2 | r0 << 1 | r2.
+// The three register bits are the three LOWEST bits of P, i.e. the three HIGHEST of its bit reversal:
+//     2 bitrev(P) + 1 = o_lane + 512 k_m,   k_m = r1 + 2 r0 + 4 r2,   o_lane < 512 (lane and wave bits only),
+// and psi^512 = omega is a primitive EIGHTH root of unity.  So zeta^e = psi^(e o_lane) omega^(e k_m mod 8): ONE table look-up
+// per lane and exponent (psi^x, x < 2N, from the table in global memory: three gathers per step where the two-wave kernel does
+// 48 from LDS, with their bank conflicts), three products by the constants omega, omega^2, omega^3, and per register a
+// wave-uniform choice among +-(A, A omega, A omega^2, A omega^3).
+template <int LOGN>
+__global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
+    using W = WavesNtt<LOGN, 2>;
+    using Part = typename W::Half;
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M, EP = W::EP, LOGE = W::LOGE;
+    static_assert(LOGN == 11 && E == 8 && std::is_same<Part, LaneNtt512>::value, "written for 512-point parts at 8 coefficients per lane");
+    // LDS (doubles): [2][N] hand-over; [2][N] re-deal + private exchange of the forward transform; [2][N] the same for the inverse
+    // (its own words: no barrier separates a step's last read of them from the next step's first write of the forward ones);
+    // the inverse per-lane twiddles.  131 KB.
+    __shared__ double lds_all[6 * N + CuTwiddles<Part, false>::LDS_WORDS];
+    const uint32_t comp = threadIdx.x >> 8, t = threadIdx.x & (LANES - 1);
+    const uint32_t w = W::wave_of(t), ln = t & 63u;
+    double *hand_mine = lds_all + comp * N, *hand_partner = lds_all + (comp ^ 1u) * N;
+    double *xf = lds_all + 2 * N + comp * N, *xb = lds_all + 4 * N + comp * N;
+    const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
+    CuTwiddles<Part, false> tw;
+    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 6 * N);
+
+    const bool live = (size_t)blockIdx.x < a.count;
+    const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
+    size_t gate, ms_row;
+    gate_of(a.gv, f, &gate, &ms_row);
+    uint32_t table = a.gv.table_ids ? a.gv.table_ids[gate] : 0;
+    if (table >= a.n_tables) table = 0;
+    const uint32_t *ms = a.ms + ms_row * (a.n + 1);
+    const uint64_t *tv = a.tvs + (size_t)table * N;
+
+    double acc[E];   // ACC = (0, X^{-b~} * TV), centred; register m of thread t = coefficient t + 256 m
+    {
+        const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t idx = (t + (uint32_t)LANES * m - r) & (2u * N - 1u);
+            const uint64_t v = tv[idx & (N - 1)];
+            acc[m] = comp ? fp_center(fp_from_u64((idx & N) ? fq_neg(v) : v)) : 0.0;
+        }
+    }
+    // one gadget level (the launcher checks): abar = round(acc / 2^(46 - beta)) mod B, balanced digit in two's complement
+    const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.beta));
+    const uint32_t bhalf = 1u << (a.beta - 1);
+    const double round_offset = 0.5 + fp_exp2i((int)a.beta) + (double)bhalf;
+    const double cw[3] = {big_f[1], big_f[2], big_f[3]}, iw[3] = {big_i[1], big_i[2], big_i[3]};
+    // o_lane = 2 bitrev11(512 w + (ln & 31) << 4 | (ln >> 5) << 3) + 1; omega^s = psi^(512 s), s = 1, 2, 3 (wave-uniform)
+    const uint32_t o_lane = 2u * (__builtin_bitreverse32(512u * w + ((ln & 31u) << 4) + ((ln >> 5) << 3)) >> (32 - LOGN)) + 1u;
+    const uniform_doubles psi_u = (uniform_doubles)(uintptr_t)a.psi_pow;
+    const double om1 = psi_u[512], om2 = psi_u[1024], om3 = psi_u[1536];
+    __syncthreads();   // (the inverse twiddle table is in place)
+
+    const uint32_t n_pairs = a.n / 2;
+    uint32_t e0_next = ms[0], e1_next = ms[1];
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        uint32_t e[3];
+        e[0] = __builtin_amdgcn_readfirstlane(e0_next);
+        e[1] = __builtin_amdgcn_readfirstlane(e1_next);
+        e0_next = ms[2 * i + 2 < a.n ? 2 * i + 2 : a.n];   // (the last pair re-reads the body word and ignores it)
+        e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
+        if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the workgroup)
+        e[2] = (e[0] + e[1]) & (2u * N - 1u);
+
+        // ---- what memory has to bring: psi^(e o_lane) for the three exponents, the own key words of the three samples -------
+        double A[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            const uint32_t x = __umul24(e[jj], o_lane) & (2u * N - 1u);
+            const double v = a.psi_pow[x & (N - 1)];
+            A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));   // psi^(x + N) = -psi^x
+        }
+        double2 ko[3][E / 2];
+        const double2 *k_oth[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            const double *krow = a.bsk_hat + ((((size_t)i * 3 + jj) * 2 + comp) * 2) * N;   // rows = 2 l = 2: row index = comp
+            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
+            k_oth[jj] = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) ko[jj][j] = k_own[j * LANES + t];
+        }
+
+        // ---- ACC_c itself, rounded to the closest multiple of q / B; the two cross stages; re-deal; private transform -------
+        double x[1][E];
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t d = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ bhalf;
+            x[0][m] = (double)(int)__builtin_amdgcn_sbfe(d, 0, a.beta);
+        }
+#pragma unroll
+        for (int m = 0; m < E / 2; m++) first_butterfly<0>(x[0][m], x[0][m + E / 2], cw[0]);
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            if (m & (E / 4)) continue;
+            const double u = x[0][m], v = fp_mulmod(x[0][m + E / 4], cw[1 + (m >> (LOGE - 1))]);
+            x[0][m] = u + v;
+            x[0][m + E / 4] = u - v;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < EP; r++) xf[q * M + t + (uint32_t)LANES * r] = x[0][q * EP + r];
+        __syncthreads();
+        double *bufs[1] = {xf + w * M};
+#pragma unroll
+        for (int m = 0; m < E; m++) x[0][m] = bufs[0][ln + 64u * m];
+        tw.template forward<1>(x, bufs, ln);
+
+        // ---- the partner's key words (now that the transform's registers are free); the monomial factors ----------------------
+        double2 kt[3][E / 2];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+            for (int j = 0; j < E / 2; j++) kt[jj][j] = k_oth[jj][j * LANES + t];
+        double V[3][4];   // psi^(e o_lane) omega^s, s = 0 .. 3
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            V[jj][0] = A[jj];
+            V[jj][1] = fp_mulmod(A[jj], om1);
+            V[jj][2] = fp_mulmod(A[jj], om2);
+            V[jj][3] = fp_mulmod(A[jj], om3);
+        }
+        // zeta^e - 1 for register m: k_m = r1 + 2 r0 + 4 r2 with m = 4 r2 + 2 r1 + r0; omega^(t + 4) = -omega^t
+        auto mono = [&](int jj, int m) {
+            const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
+            const uint32_t tt = (e[jj] * km) & 7u;                                   // wave-uniform
+            const double v = (tt & 2u) ? ((tt & 1u) ? V[jj][3] : V[jj][2]) : ((tt & 1u) ? V[jj][1] : V[jj][0]);
+            return ((tt & 4u) ? -v : v) - 1.0;
+        };
+        double own[E], other[E];
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            double wo = 0.0, wt = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < 3; jj++) {
+                const double mo = mono(jj, m);
+                const double2 a_own = ko[jj][m >> 1], a_oth = kt[jj][m >> 1];
+                wo += fp_mulmod((m & 1) ? a_own.y : a_own.x, mo);
+                wt += fp_mulmod((m & 1) ? a_oth.y : a_oth.x, mo);
+            }
+            own[m] = fp_mulmod(x[0][m], wo);      // |x| < 2^49.3, |wo| < 2.4 q: within fp_mulmod's range (as in k_blind_rotate_pairs)
+            other[m] = fp_mulmod(x[0][m], wt);
+        }
+
+        // ---- hand the partner its half, private inverse, re-deal back, the two joining stages, accumulate ------------------------
+#pragma unroll
+        for (int m = 0; m < E; m++) hand_partner[(uint32_t)LANES * m + t] = other[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < E; m++) own[m] += hand_mine[(uint32_t)LANES * m + t];
+        double *ib = xb + w * M;
+        tw.inverse(own, ib, ln);
+        Part::sync();
+#pragma unroll
+        for (int m = 0; m < E; m++) ib[ln + 64u * m] = own[m];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < EP; r++) own[q * EP + r] = xb[q * M + t + (uint32_t)LANES * r];
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            if (m & (E / 4)) continue;
+            const double u = own[m], v = own[m + E / 4];
+            own[m] = u + v;
+            own[m + E / 4] = fp_mulmod(u - v, iw[1 + (m >> (LOGE - 1))]);
+        }
+#pragma unroll
+        for (int m = 0; m < E / 2; m++) {
+            const double u = own[m], v = own[m + E / 2];
+            own[m] = u + v;
+            own[m + E / 2] = fp_mulmod(u - v, iw[0]);
+        }
+#pragma unroll
+        for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
+    }
+
+    if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, N)) {
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
+    uint64_t *out = gate_out(a.gv, f, a.ct_words);
+    if (comp == 0) {
+#pragma unroll
+        for (int m = 0; m < E; m++) {
+            const uint32_t j = t + (uint32_t)LANES * m;
+            const uint64_t v = fp_to_u64(fp_canon(acc[m]));
+            if (j == 0) out[0] = v;
+            else out[N - j] = fq_neg(v);
+        }
+    } else if (t == 0) {
+        out[N] = fq_add(fp_to_u64(fp_canon(acc[0])), a.post[table]);
+    }
+}
+
+bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
+    const fbs_params &p = ctx->p;
+    if (ctx->group != 2 || !ctx->d_bsk_hat_small || p.log_n_poly != 11 || p.l_bsk != 1 || !ctx->tune.br_cu_kernel) return false;
+    BrArgs b = a;
+    b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
+    *kernel = "k_blind_rotate_cu_pairs<11>";
+    hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+    return true;
+}
+
 bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
     // N = 1024 with up to four gadget levels, N = 2048 with up to two (LDS: 2 N + 2 l N words + the inverse twiddles)
@@ -362,6 +581,7 @@ void blind_rotate_cu_catalog(std::vector<std::string> *out) {
     for (int nl = 1; nl <= 2; nl++)
         for (int first = 0; first < 3; first++)
             out->push_back("k_blind_rotate_cu<11," + std::to_string(nl) + "," + std::to_string(first) + ">");
+    out->push_back("k_blind_rotate_cu_pairs<11>");
 }
 
 }  // namespace fbs
