@@ -12,8 +12,15 @@ root = sys.argv[1]
 
 def short(name):
     m = re.search(r"(k_[a-z_]+)\s*(<[^>]*>)?", name)
-    # (the kernel trace prints defaulted template arguments: k_blind_rotate<10,6,3,4,true> is the launcher's k_blind_rotate<10,6,3,4>)
-    return (m.group(1) + (m.group(2) or "")).replace(" ", "").replace(",true>", ">") if m else name
+    if not m:
+        return name
+    k = (m.group(1) + (m.group(2) or "")).replace(" ", "")
+    # the kernel trace prints defaulted template arguments; the launcher's names (fbs_profile_kernel, fbs_kernel_catalog) leave
+    # them out: k_blind_rotate<10,6,3,4,true> is k_blind_rotate<10,6,3,4>, k_blind_rotate_cu<10,3,2,false> is k_blind_rotate_cu<10,3,2>
+    # and k_blind_rotate_cu<10,3,2,true> its `lean` variant
+    if k.startswith("k_blind_rotate_cu<"):
+        return k.replace(",false>", ">").replace(",true>", ",lean>")
+    return k.replace(",true>", ">")
 
 
 out = collections.defaultdict(dict)
