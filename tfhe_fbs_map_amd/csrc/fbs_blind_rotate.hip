@@ -435,23 +435,27 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             auto consume = [&](auto jc, const PairKeys &in) {
                 constexpr int j = decltype(jc)::value;
                 // ... and zeta^e - 1 for its two registers and the three exponents, from the table of psi^x in LDS
+                // One look-up per exponent serves BOTH registers of the pair: 2j and 2j + 1 differ in bit 0 of their array position,
+                // i.e. in the top bit of its reversal, so their evaluation points differ by psi^N = -1 and zeta_(2j+1)^e = (-1)^e
+                // zeta_(2j)^e -- a wave-uniform sign (round 3: half the gathers from the table, and half their bank conflicts).
+                static_assert(W::eval_position_reg(1) - W::eval_position_reg(0) == 1, "registers 2j, 2j+1 hold neighbouring array positions");
                 double mono[3][2];
 #pragma unroll
-                for (int jj = 0; jj < 3; jj++)
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const uint32_t c_m = 2u * (__builtin_bitreverse32(W::eval_position_reg(2 * j + u)) >> (32 - LOGN));
-                        const uint32_t rsum = r_lane + (c_m & (G - 1));                       // uniform from here ...
-                        const uint32_t ku = (c_m >> GLOG) + (rsum >> GLOG), ru = rsum & (G - 1);
-                        const uint32_t eru = e_lv[jj] * ru;
-                        const uint32_t u8 = (e_lv[jj] * ku + (eru >> GLOG)) << 3;
-                        const uint32_t sbase = psi_base + (eru & (G - 1)) * (uint32_t)(N / G * 8);    // ... to here
-                        const uint32_t t8 = lane8[jj] + u8;
-                        const double v = *reinterpret_cast<const __attribute__((address_space(3))) double *>((t8 & MASK8) | sbase);
-                        // (+-) by the bit above the table index, then - 1
-                        const int hi = __double2hiint(v) ^ (int)((t8 << (31 - 3 - (LOGN - GLOG))) & 0x80000000u);
-                        mono[jj][u] = __hiloint2double(hi, __double2loint(v)) - 1.0;
-                    }
+                for (int jj = 0; jj < 3; jj++) {
+                    const uint32_t c_m = 2u * (__builtin_bitreverse32(W::eval_position_reg(2 * j)) >> (32 - LOGN));
+                    const uint32_t rsum = r_lane + (c_m & (G - 1));                       // uniform from here ...
+                    const uint32_t ku = (c_m >> GLOG) + (rsum >> GLOG), ru = rsum & (G - 1);
+                    const uint32_t eru = e_lv[jj] * ru;
+                    const uint32_t u8 = (e_lv[jj] * ku + (eru >> GLOG)) << 3;
+                    const uint32_t sbase = psi_base + (eru & (G - 1)) * (uint32_t)(N / G * 8);
+                    const uint32_t odd = e_lv[jj] << 31;                                   // ... to here
+                    const uint32_t t8 = lane8[jj] + u8;
+                    const double v = *reinterpret_cast<const __attribute__((address_space(3))) double *>((t8 & MASK8) | sbase);
+                    // (+-) by the bit above the table index, then - 1
+                    const int hi = __double2hiint(v) ^ (int)((t8 << (31 - 3 - (LOGN - GLOG))) & 0x80000000u);
+                    mono[jj][0] = __hiloint2double(hi, __double2loint(v)) - 1.0;
+                    mono[jj][1] = __hiloint2double(hi ^ (int)odd, __double2loint(v)) - 1.0;
+                }
                 // key words of the bundle: lazy sums of three exact products (< 2.3 q).  With |x| < 2^49.3 (general first
                 // stage) the product below stays within 0.9 q as it is; the two-FMA first stage leaves |x| near 2^51 and
                 // wants the word centred first.

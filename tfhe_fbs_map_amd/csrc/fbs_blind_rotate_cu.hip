@@ -28,10 +28,8 @@
 
 namespace fbs {
 
-// NL: gadget levels (compile time: the levels' transforms are interleaved in registers); FIRST: what is known about the digits
-// (first_butterfly, fbs_ntt.hpp): 2 = beta <= 7, 1 = beta <= 9, 0 = nothing.
 #ifndef FBS_CU_WAVES_PER_EU
-#define FBS_CU_WAVES_PER_EU 2   // waves per SIMD the compiler must leave room for (4: two workgroups per CU, at most 128 registers per thread)
+#define FBS_CU_WAVES_PER_EU 2   // waves per SIMD the compiler must leave room for in the standard variant (experiments)
 #endif
 // The twiddles a wave needs for its part, both directions, and the two calls the kernel makes with them.  Every transform a
 // lane ever runs uses the same ones.  256-point parts (N = 1024): 9 + 9 per-lane doubles, all in registers.  512-point parts
@@ -95,6 +93,8 @@ struct CuTwiddles<LaneNtt512, LEAN> {
     }
 };
 
+// NL: gadget levels (compile time: the levels' transforms are interleaved in registers); FIRST: what is known about the digits
+// (first_butterfly, fbs_ntt.hpp): 2 = beta <= 7, 1 = beta <= 9, 0 = nothing.
 // LEAN: the variant for launches of between one and two bootstraps per CU -- 128 registers per thread, so that two workgroups
 // share a CU and fill each other's barrier and LDS stalls: the partner component's key words and the inverse twiddles are
 // requested after the forward transforms instead of being held through them.
