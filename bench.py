@@ -18,9 +18,13 @@ Inputs and outputs are resident in HBM.  Time is the max over ranks between barr
 `python -m torch.distributed.run` as a child process before anything here touches the GPU, relays rank 0's JSON line
 and exits with the child's code.  With WORLD_SIZE set (the driver's own torchrun) it is a rank.
 
-Prints ONE JSON line (rank 0): the contract fields, `roofline` for the dominant kernel (blind rotation, timed live with
-HIP events on its own stream through libfbsexec's profile hooks), and at N=1 `cpu_baseline` (the CPU oracle on a
-bounded sample of the same batch) and `secure` (the same batch at the 128-bit-secure parameter set for p = 15).
+Prints ONE JSON line (rank 0): the contract fields; `roofline` for the dominant kernel (blind rotation, timed live with HIP
+events on its own stream through libfbsexec's profile hooks: `frac` = ALGORITHMIC work over time over the FP64 issue peak,
+`valu_frac` = executed instructions from the offline PMC record of profiles/r03/, refused when taken on other kernel sources);
+at N = 1 `cpu_baseline` (the scalar CPU oracle on a bounded sample of the same batch, and `tuned`: the AVX-512 IFMA baseline,
+both checked bit for bit against the GPU's ciphertexts), `secure` (the same batch at the 128-bit parameter sets) and
+`shared_rotations`; at N > 1 `sharded`: one mapped circuit cut over the ranks three ways (gate groups with one RCCL all-gather
+per level, sample groups, and the layout distributed.choose_sharding picks), strong scaling, next to the weak-scaling headline.
 """
 import argparse
 import json
