@@ -98,6 +98,8 @@ def measure(name, T, ranks_list, all_ranks, secure):
             total = widths[L] * T
             with Timer() as t_full:
                 boot(L, 0, T, 0, total, False)
+            if L % 8 == 0:      # (a long run must keep talking: a silent command is taken for hung after a few minutes)
+                print("  %s T=%d %s pass, level %d / %d" % (name, T, "warm-up" if warm else "timed", L, prog.depth), file=sys.stderr, flush=True)
             if not warm:
                 single.append(dict(level=L, width=widths[L], bootstraps=total, lincomb_ms=t_lin.ms, bootstrap_ms=t_full.ms))
             for (G, label), (gs, gg) in layouts.items():
