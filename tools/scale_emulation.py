@@ -33,7 +33,8 @@ from tfhe_fbs_map_amd.distributed import GpuBackend, allgather_ms, choose_shardi
 
 CONFIGS = {"adder128__search_p15": "BASELINE configs[0]/[1] stand-in (EPFL adder.blif is fetched from the network by the reference)",
            "mul16__search_p15": "BASELINE configs[2] stand-in (ISCAS85 c6288 = 16x16 multiplier)",
-           "trivium_stream_v2__search_p15": "BASELINE configs[3] stand-in (EPFL log2.blif is not available offline)"}
+           "trivium_stream_v2__search_p15": "BASELINE configs[3] stand-in (EPFL log2.blif is not available offline)",
+           "adder128__search_p31": "BASELINE configs[4] (fbs_size = 31): the 128-bit adder mapped @31; run with --secure (p = 31 at N = 2048, l = 2)"}
 
 
 class Timer:
