@@ -48,9 +48,13 @@ def recipe(name):
     if m:
         L, dig = int(m.group(1)), int(m.group(3))
         l, beta = {4: (1, 20), 3: (2, 7), 0: (2, 10)}[dig]
-        return dict(log_n=L, l=l, beta=beta, group=2, count=CUS + 40 if (L, l) == (11, 1) else 40, knobs={})
-    if name == "k_blind_rotate_cu_pairs<11>":             # two key bits per step on a whole CU: up to one bootstrap per CU
+        # (N = 2048 with two levels goes to the whole-CU kernel whatever the size: the A/B switch brings the generic one back)
+        return dict(log_n=L, l=l, beta=beta, group=2, count=CUS + 40 if (L, l) == (11, 1) else 40,
+                    knobs=dict(br_cu_kernel=0) if (L, l) == (11, 2) else {})
+    if name == "k_blind_rotate_cu_pairs<11,1>":           # two key bits per step on a whole CU: up to one bootstrap per CU
         return dict(log_n=11, l=1, beta=20, group=2, count=CUS - 9, knobs={})
+    if name == "k_blind_rotate_cu_pairs<11,2>":           # ... with two gadget levels: every launch, round after round
+        return dict(log_n=11, l=2, beta=10, group=2, count=CUS + 21, knobs={})
     m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))

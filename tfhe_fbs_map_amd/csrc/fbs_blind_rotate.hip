@@ -556,8 +556,8 @@ static int upload_keys_t(fbs_ctx *ctx) {
         e = hipGetLastError();
         constexpr int LLS = lanes_log2_for_small_launch(LOGN);
         if constexpr (LLS != LL) {
-            // (two key bits per step: a second copy of the 1.5 times larger key only where a kernel reads it -- N = 2048, l = 1)
-            if (ctx->group == 1 || (LOGN == 11 && ctx->p.l_bsk == 1)) {
+            // (two key bits per step: a second copy of the 1.5 times larger key only where a kernel reads it -- N = 2048, l <= 2)
+            if (ctx->group == 1 || (LOGN == 11 && ctx->p.l_bsk <= 2)) {
                 if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL((k_bsk_transform<LOGN, LLS>), dim3(grid), dim3(1 << LLS), 0, ctx->stream, d_src,
@@ -684,7 +684,9 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
         // launches of at most one bootstrap per CU: the whole-CU shape (2.65-2.9 ms per bootstrap against 3.3-3.4; two rounds of
         // it are no faster than two bootstraps side by side in the four-wave kernel: 5.44 against 5.35 ms per 512)
-        if (count <= (size_t)ctx->cu_count && ctx->tune.br_cu_max_per_cu >= 1) {
+        // Two gadget levels (the 128-bit sets for p = 31): the whole-CU shape for every launch, round after round -- the
+        // two-waves-per-polynomial kernel spills 100 registers there (22.7 ms per 1024 bootstraps against 17.1)
+        if ((count <= (size_t)ctx->cu_count || p.l_bsk == 2) && ctx->tune.br_cu_max_per_cu >= 1) {
             hipEvent_t c0, c1;
             prof_begin(ctx, 1, stream, &c0, &c1);
             if (launch_blind_rotate_cu_pairs(ctx, a, stream, &ctx->prof.kernel[1])) {

@@ -331,23 +331,29 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
 // per lane and exponent (psi^x, x < 2N, from the table in global memory: three gathers per step where the two-wave kernel does
 // 48 from LDS, with their bank conflicts), three products by the constants omega, omega^2, omega^3, and per register a
 // wave-uniform choice among +-(A, A omega, A omega^2, A omega^3).
-template <int LOGN>
+// NL gadget levels (1: the p = 15 sets; 2: what p = 31 takes with two key bits per step): the levels' forward transforms run
+// together (forward_multi), and the key words -- 6 NL polynomials per component and step -- are fetched register pair by
+// register pair while the bundle of the pair before is built, instead of being held through the transforms.
+template <int LOGN, int NL>
 __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     using W = WavesNtt<LOGN, 2>;
     using Part = typename W::Half;
     constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M, EP = W::EP, LOGE = W::LOGE;
     static_assert(LOGN == 11 && E == 8 && std::is_same<Part, LaneNtt512>::value, "written for 512-point parts at 8 coefficients per lane");
-    // LDS (doubles): [2][N] hand-over; [2][N] re-deal + private exchange of the forward transform; [2][N] the same for the inverse
-    // (its own words: no barrier separates a step's last read of them from the next step's first write of the forward ones);
-    // the inverse per-lane twiddles.  131 KB.
-    __shared__ double lds_all[6 * N + CuTwiddles<Part, false>::LDS_WORDS];
+    static_assert(NL == 1 || NL == 2, "one or two gadget levels");
+    // LDS (doubles): [2][N] hand-over, then the inverse transform's private exchange and the re-deal back -- wave w of a component
+    // receives its hand-over words in [w M, (w + 1) M), the words it alone touches until the re-deal, so the three uses need no
+    // barrier beyond the two they have (the next step's hand-over lies behind that step's re-deal barrier); [2][NL][N] re-deal +
+    // private exchange of the forward transforms; the inverse per-lane twiddles.  100 KB (NL = 1), 133 KB (NL = 2).
+    __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part, false>::LDS_WORDS];
     const uint32_t comp = threadIdx.x >> 8, t = threadIdx.x & (LANES - 1);
     const uint32_t w = W::wave_of(t), ln = t & 63u;
-    double *hand_mine = lds_all + comp * N, *hand_partner = lds_all + (comp ^ 1u) * N;
-    double *xf = lds_all + 2 * N + comp * N, *xb = lds_all + 4 * N + comp * N;
+    double *back = lds_all + comp * N;
+    double *hand_mine = back + w * M, *hand_partner = lds_all + (comp ^ 1u) * N + w * M;
+    double *xf = lds_all + 2 * N + comp * (NL * N);
     const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
     CuTwiddles<Part, false> tw;
-    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 6 * N);
+    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 2 * N + 2 * NL * N);
 
     const bool live = (size_t)blockIdx.x < a.count;
     const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     if (table >= a.n_tables) table = 0;
     const uint32_t *ms = a.ms + ms_row * (a.n + 1);
     const uint64_t *tv = a.tvs + (size_t)table * N;
+    constexpr uint32_t rows = 2 * NL;
 
     double acc[E];   // ACC = (0, X^{-b~} * TV), centred; register m of thread t = coefficient t + 256 m
     {
@@ -368,10 +375,17 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             acc[m] = comp ? fp_center(fp_from_u64((idx & N) ? fq_neg(v) : v)) : 0.0;
         }
     }
-    // one gadget level (the launcher checks): abar = round(acc / 2^(46 - beta)) mod B, balanced digit in two's complement
-    const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.beta));
+    // rounding / digit constants: as in k_blind_rotate (abar = round(acc / 2^(46 - NL beta)) mod B^NL, balanced digits packed in
+    // two's complement fields)
+    const double round_scale = fp_exp2i(-(int)(FQ_BITS - NL * a.beta));
     const uint32_t bhalf = 1u << (a.beta - 1);
-    const double round_offset = 0.5 + fp_exp2i((int)a.beta) + (double)bhalf;
+    double round_offset = 0.5 + fp_exp2i((int)(NL * a.beta));
+    uint32_t sign_bits = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < NL; j++) {
+        round_offset += (double)(bhalf << (j * a.beta));
+        sign_bits |= bhalf << (j * a.beta);
+    }
     const double cw[3] = {big_f[1], big_f[2], big_f[3]}, iw[3] = {big_i[1], big_i[2], big_i[3]};
     // o_lane = 2 bitrev11(512 w + (ln & 31) << 4 | (ln >> 5) << 3) + 1; omega^s = psi^(512 s), s = 1, 2, 3 (wave-uniform)
     const uint32_t o_lane = 2u * (__builtin_bitreverse32(512u * w + ((ln & 31u) << 4) + ((ln >> 5) << 3)) >> (32 - LOGN)) + 1u;
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the workgroup)
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
 
-        // ---- what memory has to bring: psi^(e o_lane) for the three exponents, the own key words of the three samples -------
+        // ---- what memory has to bring: psi^(e o_lane) for the three exponents, and the key words -----------------------------
         double A[3];
 #pragma unroll
         for (int jj = 0; jj < 3; jj++) {
@@ -398,95 +412,141 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             const double v = a.psi_pow[x & (N - 1)];
             A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));   // psi^(x + N) = -psi^x
         }
-        double2 ko[3][E / 2];
-        const double2 *k_oth[3];
+        // row (jj, comp NL + lv) of step i: its own column (this component's products) and the partner's
+        const double *kstep = a.bsk_hat + (size_t)i * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N;
+        // (the key words of one register pair (2j, 2j + 1): three samples x NL rows, of the own or of the partner's column)
+        auto request = [&](auto jc, auto partner, double2 (&k)[3][NL]) {
+            constexpr int j = decltype(jc)::value;
+            const uint32_t col = decltype(partner)::value ? comp ^ 1u : comp;
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) {
-            const double *krow = a.bsk_hat + ((((size_t)i * 3 + jj) * 2 + comp) * 2) * N;   // rows = 2 l = 2: row index = comp
-            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
-            k_oth[jj] = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+            for (int jj = 0; jj < 3; jj++)
 #pragma unroll
-            for (int j = 0; j < E / 2; j++) ko[jj][j] = k_own[j * LANES + t];
-        }
-
-        // ---- ACC_c itself, rounded to the closest multiple of q / B; the two cross stages; re-deal; private transform -------
-        double x[1][E];
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            const uint32_t d = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ bhalf;
-            x[0][m] = (double)(int)__builtin_amdgcn_sbfe(d, 0, a.beta);
-        }
-#pragma unroll
-        for (int m = 0; m < E / 2; m++) first_butterfly<0>(x[0][m], x[0][m + E / 2], cw[0]);
-#pragma unroll
-        for (int m = 0; m < E; m++) {
-            if (m & (E / 4)) continue;
-            const double u = x[0][m], v = fp_mulmod(x[0][m + E / 4], cw[1 + (m >> (LOGE - 1))]);
-            x[0][m] = u + v;
-            x[0][m + E / 4] = u - v;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-#pragma unroll
-            for (int r = 0; r < EP; r++) xf[q * M + t + (uint32_t)LANES * r] = x[0][q * EP + r];
-        __syncthreads();
-        double *bufs[1] = {xf + w * M};
-#pragma unroll
-        for (int m = 0; m < E; m++) x[0][m] = bufs[0][ln + 64u * m];
-        tw.template forward<1>(x, bufs, ln);
-
-        // ---- the partner's key words (now that the transform's registers are free); the monomial factors ----------------------
-        double2 kt[3][E / 2];
-#pragma unroll
-        for (int jj = 0; jj < 3; jj++)
-#pragma unroll
-            for (int j = 0; j < E / 2; j++) kt[jj][j] = k_oth[jj][j * LANES + t];
-        double V[3][4];   // psi^(e o_lane) omega^s, s = 0 .. 3
-#pragma unroll
-        for (int jj = 0; jj < 3; jj++) {
-            V[jj][0] = A[jj];
-            V[jj][1] = fp_mulmod(A[jj], om1);
-            V[jj][2] = fp_mulmod(A[jj], om2);
-            V[jj][3] = fp_mulmod(A[jj], om3);
-        }
-        // zeta^e - 1 for register m: k_m = r1 + 2 r0 + 4 r2 with m = 4 r2 + 2 r1 + r0; omega^(t + 4) = -omega^t
-        auto mono = [&](int jj, int m) {
-            const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
-            const uint32_t tt = (e[jj] * km) & 7u;                                   // wave-uniform
-            const double v = (tt & 2u) ? ((tt & 1u) ? V[jj][3] : V[jj][2]) : ((tt & 1u) ? V[jj][1] : V[jj][0]);
-            return ((tt & 4u) ? -v : v) - 1.0;
+                for (int lv = 0; lv < NL; lv++)
+                    k[jj][lv] = reinterpret_cast<const double2 *>(kstep + ((size_t)(jj * (int)rows + lv) * 2u + col) * N)[j * LANES + t];
         };
-        double own[E], other[E];
+        using Own = std::false_type;
+        using Oth = std::true_type;
+        // Pair 0's words are requested here, ahead of the transforms; pair j + 1's when pair j has been used up.  Measured against
+        // holding more through the transforms (NL = 1: all own words, 3.09 ms per 256 bootstraps against 2.89; NL = 2: two pairs,
+        // 17.7 against 17.1 ms per 1024): what counts is that nothing is spilled.
+        double2 ko[3][NL], kt[3][NL];
+        request(std::integral_constant<int, 0>{}, Own{}, ko);
+        request(std::integral_constant<int, 0>{}, Oth{}, kt);
+
+        // ---- ACC_c itself, rounded to the closest multiple of q / B^NL; the two cross stages; re-deal; private transforms ---------
+        double x[NL][E];
+        {
+            uint32_t digits[E];
 #pragma unroll
-        for (int m = 0; m < E; m++) {
-            double wo = 0.0, wt = 0.0;
+            for (int m = 0; m < E; m++) digits[m] = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ sign_bits;
 #pragma unroll
-            for (int jj = 0; jj < 3; jj++) {
-                const double mo = mono(jj, m);
-                const double2 a_own = ko[jj][m >> 1], a_oth = kt[jj][m >> 1];
-                wo += fp_mulmod((m & 1) ? a_own.y : a_own.x, mo);
-                wt += fp_mulmod((m & 1) ? a_oth.y : a_oth.x, mo);
+            for (int lv = 0; lv < NL; lv++) {
+                const uint32_t shift = ((uint32_t)NL - 1u - (uint32_t)lv) * a.beta;
+#pragma unroll
+                for (int m = 0; m < E; m++) x[lv][m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);
+#pragma unroll
+                for (int m = 0; m < E / 2; m++) first_butterfly<0>(x[lv][m], x[lv][m + E / 2], cw[0]);
+#pragma unroll
+                for (int m = 0; m < E; m++) {
+                    if (m & (E / 4)) continue;
+                    const double u = x[lv][m], v = fp_mulmod(x[lv][m + E / 4], cw[1 + (m >> (LOGE - 1))]);
+                    x[lv][m] = u + v;
+                    x[lv][m + E / 4] = u - v;
+                }
+                double *region = xf + lv * N;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int r = 0; r < EP; r++) region[q * M + t + (uint32_t)LANES * r] = x[lv][q * EP + r];
             }
-            own[m] = fp_mulmod(x[0][m], wo);      // |x| < 2^49.3, |wo| < 2.4 q: within fp_mulmod's range (as in k_blind_rotate_pairs)
-            other[m] = fp_mulmod(x[0][m], wt);
         }
+        __syncthreads();
+        double *bufs[NL];
+#pragma unroll
+        for (int lv = 0; lv < NL; lv++) {
+            bufs[lv] = xf + lv * N + w * M;
+#pragma unroll
+            for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
+        }
+        tw.template forward<NL>(x, bufs, ln);
+
+        // ---- the monomial factors ----------------------------------------------------------------------------------------
+        // psi^(e o_lane) omega^s, s = 0 .. 3.  (Scalars, one set per exponent, on purpose: as one array indexed by the exponent's
+        // loop variable the compiler turns the selections below into indexed loads from a copy it keeps in scratch memory --
+        // 24 loads per step in the place of register selects, 3.4 ms per bootstrap instead of 2.9.)
+        struct Powers {
+            double s0, s1, s2, s3;
+        };
+        auto powers = [&](double base) {
+            if constexpr (NL == 1) return Powers{base, fp_mulmod(base, om1), fp_mulmod(base, om2), fp_mulmod(base, om3)};
+            else return Powers{base, 0.0, 0.0, 0.0};
+        };
+        const Powers V0 = powers(A[0]), V1 = powers(A[1]), V2 = powers(A[2]);
+        // zeta^e - 1 for register m: k_m = r1 + 2 r0 + 4 r2 with m = 4 r2 + 2 r1 + r0; omega^(t + 4) = -omega^t
+        // (NL = 2 has no registers for the twelve powers: there the WAVE-UNIFORM factor omega^(e k_m) is picked by scalar
+        // instructions and multiplied in -- 7 FP64 instructions per factor where the selects take 8 half-rate ones)
+        auto mono = [&](const Powers &V, uint32_t ej, int m) {
+            const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
+            const uint32_t tt = (ej * km) & 7u;                                      // wave-uniform
+            if constexpr (NL == 1) {
+                const double v = (tt & 2u) ? ((tt & 1u) ? V.s3 : V.s2) : ((tt & 1u) ? V.s1 : V.s0);
+                return ((tt & 4u) ? -v : v) - 1.0;
+            } else {
+                const double om = (tt & 2u) ? ((tt & 1u) ? om3 : om2) : ((tt & 1u) ? om1 : 1.0);
+                return fp_mulmod(V.s0, (tt & 4u) ? -om : om) - 1.0;    // |.| < 0.75 q + 1: the products below stay exact
+            }
+        };
+        // bundle words of a register (lazy sums of three exact products, < 2.4 q) times the digits' evaluations: |x| < 2^49.3,
+        // within fp_mulmod's range (as in k_blind_rotate_pairs)
+        double own[E], other[E];
+        auto consume = [&](auto jc, const double2 (&k_own)[3][NL], const double2 (&k_oth)[3][NL]) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int m = 2 * j + r;
+                const double mo[3] = {mono(V0, e[0], m), mono(V1, e[1], m), mono(V2, e[2], m)};
+#pragma unroll
+                for (int lv = 0; lv < NL; lv++) {
+                    double wo = 0.0, wt = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++) {
+                        const double2 a_own = k_own[jj][lv], a_oth = k_oth[jj][lv];
+                        wo += fp_mulmod(r ? a_own.y : a_own.x, mo[jj]);
+                        wt += fp_mulmod(r ? a_oth.y : a_oth.x, mo[jj]);
+                    }
+                    const double p = fp_mulmod(x[lv][m], wo), q = fp_mulmod(x[lv][m], wt);
+                    own[m] = lv ? own[m] + p : p;
+                    other[m] = lv ? other[m] + q : q;
+                }
+            }
+        };
+#define FBS_CU_PAIR_STEP(J)                                                                                      \
+    {                                                                                                            \
+        consume(std::integral_constant<int, (J)>{}, ko, kt);                                                     \
+        __builtin_amdgcn_sched_barrier(0);   /* (or every request is hoisted to the top, and spilled) */         \
+        if constexpr ((J) + 1 < E / 2) {                                                                         \
+            request(std::integral_constant<int, ((J) + 1) % (E / 2)>{}, Own{}, ko);                              \
+            request(std::integral_constant<int, ((J) + 1) % (E / 2)>{}, Oth{}, kt);                              \
+        }                                                                                                        \
+    }
+        FBS_CU_PAIR_STEP(0) FBS_CU_PAIR_STEP(1) FBS_CU_PAIR_STEP(2) FBS_CU_PAIR_STEP(3)
+#undef FBS_CU_PAIR_STEP
 
         // ---- hand the partner its half, private inverse, re-deal back, the two joining stages, accumulate ------------------------
 #pragma unroll
-        for (int m = 0; m < E; m++) hand_partner[(uint32_t)LANES * m + t] = other[m];
+        for (int m = 0; m < E; m++) hand_partner[64u * m + ln] = other[m];
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < E; m++) own[m] += hand_mine[(uint32_t)LANES * m + t];
-        double *ib = xb + w * M;
-        tw.inverse(own, ib, ln);
+        for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
+        tw.inverse(own, hand_mine, ln);
         Part::sync();
 #pragma unroll
-        for (int m = 0; m < E; m++) ib[ln + 64u * m] = own[m];
+        for (int m = 0; m < E; m++) hand_mine[ln + 64u * m] = own[m];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int r = 0; r < EP; r++) own[q * EP + r] = xb[q * M + t + (uint32_t)LANES * r];
+            for (int r = 0; r < EP; r++) own[q * EP + r] = back[q * M + t + (uint32_t)LANES * r];
 #pragma unroll
         for (int m = 0; m < E; m++) {
             if (m & (E / 4)) continue;
@@ -526,11 +586,16 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
 
 bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
-    if (ctx->group != 2 || !ctx->d_bsk_hat_small || p.log_n_poly != 11 || p.l_bsk != 1 || !ctx->tune.br_cu_kernel) return false;
+    if (ctx->group != 2 || !ctx->d_bsk_hat_small || p.log_n_poly != 11 || p.l_bsk > 2 || !ctx->tune.br_cu_kernel) return false;
     BrArgs b = a;
     b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
-    *kernel = "k_blind_rotate_cu_pairs<11>";
-    hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+    if (p.l_bsk == 1) {
+        *kernel = "k_blind_rotate_cu_pairs<11,1>";
+        hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11, 1>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+    } else {
+        *kernel = "k_blind_rotate_cu_pairs<11,2>";
+        hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11, 2>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+    }
     return true;
 }
 
@@ -581,7 +646,8 @@ void blind_rotate_cu_catalog(std::vector<std::string> *out) {
     for (int nl = 1; nl <= 2; nl++)
         for (int first = 0; first < 3; first++)
             out->push_back("k_blind_rotate_cu<11," + std::to_string(nl) + "," + std::to_string(first) + ">");
-    out->push_back("k_blind_rotate_cu_pairs<11>");
+    out->push_back("k_blind_rotate_cu_pairs<11,1>");
+    out->push_back("k_blind_rotate_cu_pairs<11,2>");
 }
 
 }  // namespace fbs

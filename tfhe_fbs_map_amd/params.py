@@ -135,8 +135,10 @@ def bootstrap_cost(prm: Params) -> float:
     # two key bits per step (bsk_group = 2), MEASURED against one bit per step at the same shape (profiles/r02): 0.74 with one
     # gadget level (9.8 against 13.2 ms per 1024 bootstraps at N = 2048, n = 714 / 710).  With l levels the bundle costs
     # 6 l exact products per coefficient and pair of key bits where it saves l + 1 transforms: it does not pay beyond
-    # l = 1 (P1024, l = 3: 13.5 against 10.8 ms)
-    pairs = 1.0 if prm.bsk_group != 2 else (0.74 if l == 1 else 1.25)
+    # l = 1 in the two-waves-per-polynomial kernel (P1024, l = 3: 13.5 against 10.8 ms).  N = 2048 with TWO levels runs on the
+    # whole-CU kernel, which has the registers for it: 17.1 ms per 1024 bootstraps at n = 758 against 21.9 ms at n = 766 with one
+    # bit per step (round 3: what the 128-bit sets for p = 31 now take)
+    pairs = 1.0 if prm.bsk_group != 2 else (0.74 if l == 1 else 0.79 if (l == 2 and prm.log_n_poly == 11) else 1.25)
     return 0.988 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
