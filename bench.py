@@ -306,7 +306,8 @@ def roofline_record(prm, prof, kernels, B, steps):
                     "the key is served from L2/Infinity Cache after first touch, `traffic` is what reached the fabric")
     pmc = None
     if os.path.exists(PMC_FILE):
-        pmc = json.load(open(PMC_FILE)).get(name)
+        records = json.load(open(PMC_FILE))
+        pmc = records.get("%s@%d" % (name, units)) or records.get(name)
     if pmc is None:
         rec["pmc"] = "no record for %s in %s" % (name, os.path.relpath(PMC_FILE, ROOT))
     elif pmc.get("csrc_sha256") != kernel_sources_sha256():
@@ -363,9 +364,11 @@ def run_batch(args, rank, world, local, dist):
         # (the headline shape is BASELINE's benchmark set at reduced noise; what a deployment runs, in one line of `config`)
         p4 = sec["n1024_p4"]
         result["config"]["secure_summary"] = (
-            "128-bit parameter sets, same batch: p=15 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step); p=4 at N=1024 %.0f FBS/s (n=%d l=%d)"
+            "128-bit parameter sets, same batch: p=15 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step); p=4 at N=1024 %.0f FBS/s (n=%d l=%d); "
+            "p=31 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step)"
             % (sec["value"], sec["params"]["n"], sec["params"]["N"], sec["params"]["l"], sec["params"]["key_bits_per_step"],
-               p4["value"], p4["params"]["n"], p4["params"]["l"]))
+               p4["value"], p4["params"]["n"], p4["params"]["l"], sec["p31"]["value"], sec["p31"]["params"]["n"],
+               sec["p31"]["params"]["N"], sec["p31"]["params"]["l"], sec["p31"]["params"]["key_bits_per_step"]))
     return result
 
 
@@ -456,6 +459,11 @@ def secure_leg(B, local, steps):
     # reference's own Trivium / Kreyvium comparison point (experiments/analyse_results.py:317)
     small = choose_params(4, 2)
     rec["n1024_p4"] = dict(one(small), note="128-bit set for p = 4 at norm2 = 2: the N = 1024 kernels at a secure parameter set")
+    # BASELINE configs[4] (fbs_size = 31; no non-power-of-two N here: the 128-bit set is N = 2048 with two gadget levels)
+    big = choose_params(31, 325)
+    rec["p31"] = dict(one(big), note="128-bit set for p = 31 at norm2 = 325 (BASELINE configs[4]: fbs_size = 31)")
+    if rec["p31"]["params"]["key_bits_per_step"] != 1:
+        rec["p31"]["one_key_bit_per_step"] = one(choose_params(31, 325, groups=(1,)))
     return rec
 
 

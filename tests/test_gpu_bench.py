@@ -42,6 +42,7 @@ def test_headline_line_has_the_contract_fields():
     s = d["secure"]
     assert s["decrypt_ok"] and s["params"]["security_bits_estimate"] >= 127.9 and s["margin_sigmas_at_norm2_70"] >= 6.0
     assert s["n1024_p4"]["decrypt_ok"] and s["n1024_p4"]["params"]["N"] == 1024
+    assert s["p31"]["decrypt_ok"] and s["p31"]["params"]["security_bits_estimate"] >= 127.9 and s["p31"]["params"]["p"] == 31
     f = d["shared_rotations"]                                                # several tables on one blind rotation
     assert f["plain"]["all_sums_correct"] and f["fused"]["all_sums_correct"]
     assert f["fused"]["blind_rotations"] < f["fused"]["tables"] == f["plain"]["tables"] == f["plain"]["blind_rotations"]

@@ -17,9 +17,10 @@ rec p1024 630 1 1024
 rec cu256 630 1 256
 rec secure 714 2 1024
 rec secure1 710 1 1024
-rec p31 766 1 1024
+rec p31 766 2 1024
+rec p31g1 766 1 1024
 rec p63 822 1 1024
 rec p4 638 1 1024
 rec secure256 714 2 256
-rec p31cu 766 1 256
+rec p31cu 766 2 256
 rec lean512 630 1 512

@@ -36,6 +36,7 @@ for kernel, rec in data.items():
         # conversions, 64-bit integer); the 32-bit ones 2 (MI355X_MICROARCH.md, v_fma_f32 at two waves per SIMD)
         entry["valu_mix_per_launch"] = {c: pmc[c] for c in pmc if c.startswith("SQ_INSTS_VALU_")}
         entry["valu_64bit_per_launch"] = pmc["SQ_INSTS_VALU"] - pmc["SQ_INSTS_VALU_INT32"]
-    out[kernel] = entry
+    # (a kernel profiled at two launch sizes: the first under its name, the others under name@units -- bench.py tries that first)
+    out[kernel if out.get(kernel, entry)["units_per_launch"] == units else "%s@%d" % (kernel, units)] = entry
 json.dump(out, open(record, "w"), indent=1)
 print(json.dumps({k: v["valu_per_wave_per_step"] for k, v in out.items()}))

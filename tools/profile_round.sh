@@ -3,7 +3,8 @@
 # in), for a list of (name, command) sets; summarised per kernel by tools/profile_summary.py.
 #   usage (on the GPU box): bash tools/profile_round.sh <tag> [set ...]      -> gpurun_out/prof_<tag>/<set>/
 #   sets: p1024 (bench.py headline), cu256 (bench.py --batch 256: one bootstrap per CU), secure (128-bit p = 15, two key bits per
-#         step), secure1 (one key bit per step), p31 (config 5: 128-bit set for p = 31), p63 (N = 4096), p4 (N = 1024 128-bit set),
+#         step), secure1 (one key bit per step), p31 (config 5: 128-bit set for p = 31, two key bits per step on whole CUs),
+#         p31g1 (the same with one key bit per step), p63 (N = 4096, one key bit per step), p4 (N = 1024 128-bit set),
 #         secure256 / p31cu (the p = 15 and p = 31 sets at one bootstrap per CU), lean512 (bench.py --batch 512: two workgroups per CU)
 TAG=${1:-r03}; shift
 SETS=${@:-p1024 cu256 secure p31}
@@ -32,6 +33,7 @@ for S in $SETS; do
     secure)  run_set secure python3 tools/secure_bench.py 1024 5 15 70 ;;
     secure1) run_set secure1 python3 tools/secure_bench.py 1024 5 15 70 1 ;;
     p31)     run_set p31 python3 tools/secure_bench.py 1024 4 31 325 ;;
+    p31g1)   run_set p31g1 python3 tools/secure_bench.py 1024 4 31 325 1 ;;
     p63)     run_set p63 python3 tools/secure_bench.py 1024 3 63 100 ;;
     p4)      run_set p4 python3 tools/secure_bench.py 1024 5 4 2 ;;
     secure256) run_set secure256 python3 tools/secure_bench.py 256 8 15 70 ;;
