@@ -35,6 +35,9 @@ SETS = {
                                              sigma_lwe=1065975446, sigma_glwe=4, bsk_group=2),
     "secure_p31": dict(n=766, log_n_poly=11, k=1, l_bsk=2, beta_bsk=14, t_ksk=8, gamma_ksk=2, p_msg=31, sigma_lwe=408668278,
                        sigma_glwe=4, bsk_group=1),
+    # (round 3: what the selector returns for (31, 325) since two key bits per step with two gadget levels have their kernel)
+    "secure_p31_two_key_bits_per_step": dict(n=766, log_n_poly=11, k=1, l_bsk=2, beta_bsk=14, t_ksk=8, gamma_ksk=2, p_msg=31,
+                                             sigma_lwe=408668278, sigma_glwe=4, bsk_group=2),
     "secure_p4_n1024": dict(n=638, log_n_poly=10, k=1, l_bsk=2, beta_bsk=8, t_ksk=12, gamma_ksk=1, p_msg=4, sigma_lwe=4328098537,
                             sigma_glwe=3511592, bsk_group=1),
 }
