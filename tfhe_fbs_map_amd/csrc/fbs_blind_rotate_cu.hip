@@ -22,12 +22,53 @@
 // 128-register workgroups per CU) 5.4 ms for 512.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <type_traits>
 
 #include "fbs_blind_rotate.hpp"
 
 namespace fbs {
 
+// -DFBS_CU_TRACE (experiments only, tools/variant builds): cycles per phase of a step, per wave of workgroup 0, summed over the
+// rotation and printed by the launcher -- where a step's time goes when the instruction count says it should be shorter
+#ifdef FBS_CU_TRACE
+__device__ unsigned long long g_cu_trace[8 * 16];
+#define FBS_TRACE_INIT unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FBS_TRACE(k)                                              \
+    {                                                             \
+        const unsigned long long now = __builtin_readcyclecounter(); \
+        tr_acc[k] += now - tr_t;                                  \
+        tr_t = now;                                               \
+    }
+#define FBS_TRACE_FLUSH                                           \
+    if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0)              \
+        for (int k = 0; k < 12; k++) g_cu_trace[(threadIdx.x >> 6) * 16 + k] = tr_acc[k];
+#else
+#define FBS_TRACE_INIT
+#define FBS_TRACE(k)
+#define FBS_TRACE_FLUSH
+#endif
+// Issue priority between the two waves of a SIMD (wave w of component 0 and wave w of component 1).  Left alone the SIMD issues
+// the OLDER wave first whenever both are ready: component 0 runs every stretch between two barriers at full speed, waits at
+// the barrier, and component 1 finishes it ALONE, with nobody to fill its stalls (traced with -DFBS_CU_TRACE at P1024: of a
+// 7.0 M-cycle rotation component 0 spends 2.9 M waiting at barriers while component 1 issues at 54 % of the rate the pair
+// reaches together).  favour() flips the lead in the middle of a stretch -- component 1 leads the first half, component 0
+// the second -- so both arrive at the barrier together.  FBS_CU_PRIO: 0 off, 1 the long stretch only (forward transforms |
+// products), 2 also the inverse transform (before | after its exchange).  Measured at P1024 (64 / 256 bootstraps): 3.02 / 3.10
+// -> 2.95 / 3.05 -> 2.92 / 3.00 ms per step; flipping in the rotation-and-digits stretch as well: no further gain.  What remains
+// is not imbalance: two waves per SIMD issue one FP64 instruction per 4.8-5.4 cycles at best (profiles/r01/fp64_issue_rate.txt).
+#ifndef FBS_CU_PRIO
+#define FBS_CU_PRIO 2
+#endif
+// (`me` must be WAVE-UNIFORM, a scalar register: on a value derived from threadIdx the compiler predicates both s_setprio
+// with the exec mask, which scalar instructions ignore -- every wave then runs both and ends at priority 1.)
+template <int LEVEL>
+__device__ __forceinline__ void favour(bool me) {
+    if constexpr (FBS_CU_PRIO >= LEVEL) {
+        if (me) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+}
 #ifndef FBS_CU_WAVES_PER_EU
 #define FBS_CU_WAVES_PER_EU 2   // waves per SIMD the compiler must leave room for in the standard variant (experiments)
 #endif
@@ -60,7 +101,10 @@ struct CuTwiddles<LaneNtt256, LEAN> {
     __device__ __forceinline__ void prefetch_inverse() {
         if constexpr (LEAN) i = LaneNtt256::load(inv_part, inv_big, root, lane);
     }
-    __device__ __forceinline__ void inverse(double (&x)[4], double *buf, uint32_t ln) const { LaneNtt256::inverse_one(x, buf, ln, i); }
+    template <class Hook>
+    __device__ __forceinline__ void inverse(double (&x)[4], double *buf, uint32_t ln, Hook &&mid) const {
+        LaneNtt256::inverse_one(x, buf, ln, i, mid);
+    }
 };
 template <bool LEAN>
 struct CuTwiddles<LaneNtt512, LEAN> {
@@ -88,8 +132,9 @@ struct CuTwiddles<LaneNtt512, LEAN> {
         LaneNtt512::forward_multi<NL, 0>(x, bufs, ln, uf, f, LaneNtt512::NoHook{});
     }
     __device__ __forceinline__ void prefetch_inverse() {}
-    __device__ __forceinline__ void inverse(double (&x)[8], double *buf, uint32_t ln) const {
-        LaneNtt512::inverse_one(x, buf, ln, ui, LaneNtt512::load_lane_table(inv_table, ln));
+    template <class Hook>
+    __device__ __forceinline__ void inverse(double (&x)[8], double *buf, uint32_t ln, Hook &&mid) const {
+        LaneNtt512::inverse_one(x, buf, ln, ui, LaneNtt512::load_lane_table(inv_table, ln), mid);
     }
 };
 
@@ -158,10 +203,13 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     __syncthreads();
 
     uint32_t r_next = ms[0];
+    const bool second = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0u;   // this wave belongs to component 1 (scalar)
+    FBS_TRACE_INIT
     for (uint32_t i = 0; i < a.n; i++) {
         const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
         r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
         if (r == 0) continue;   // X^0 * ACC - ACC = 0 (uniform over the workgroup: no barrier is skipped by part of it)
+        FBS_TRACE(0)
 
         // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
         // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
@@ -191,6 +239,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
                 digits[m] = (uint32_t)__builtin_fma(d, round_scale, round_offset) ^ sign_bits;
             }
         }
+        FBS_TRACE(1)
 
         // ---- all levels: digits -> the two cross stages -> re-deal -> private transforms, together ------------------------
         double x[NL][E];
@@ -215,7 +264,10 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
 #pragma unroll
                 for (int r = 0; r < EP; r++) region[q * M + t + (uint32_t)LANES * r] = x[lv][q * EP + r];
         }
+        FBS_TRACE(2)
         __syncthreads();
+        FBS_TRACE(3)
+        if constexpr (!LEAN) favour<1>(second);
         double *bufs[NL];
 #pragma unroll
         for (int lv = 0; lv < NL; lv++) {
@@ -224,6 +276,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
             for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
         }
         tw.template forward<NL>(x, bufs, ln);
+        FBS_TRACE(4)
+        if constexpr (!LEAN) favour<1>(!second);
         if constexpr (LEAN) {   // what the forward transforms had no registers for
 #pragma unroll
             for (int lv = 0; lv < NL; lv++) {
@@ -258,15 +312,22 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
             // ---- hand the partner its half (through the accumulator words: every rotation has read them by now) ---------
 #pragma unroll
             for (int m = 0; m < E; m++) accbuf_partner[(uint32_t)LANES * m + t] = other[m];
+            FBS_TRACE(5)
             __syncthreads();
+            FBS_TRACE(6)
+            if constexpr (!LEAN) favour<2>(second);
 #pragma unroll
             for (int m = 0; m < E; m++) own[m] += accbuf[(uint32_t)LANES * m + t];
             // ---- private inverse, re-deal back -----------------------------------------------------------------------
-            tw.inverse(own, bufs[0], ln);
+            tw.inverse(own, bufs[0], ln, [&] {
+                if constexpr (!LEAN) favour<2>(!second);
+            });
             Part::sync();
 #pragma unroll
             for (int m = 0; m < E; m++) bufs[0][ln + 64u * m] = own[m];
+            FBS_TRACE(7)
             __syncthreads();
+            FBS_TRACE(8)
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -291,8 +352,11 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
             acc[m] = fp_center(acc[m] + own[m]);
             accbuf[t + (uint32_t)LANES * m] = acc[m];
         }
+        FBS_TRACE(9)
         __syncthreads();
+        FBS_TRACE(10)
     }
+    FBS_TRACE_FLUSH
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
     if (!live) return;
@@ -538,7 +602,8 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
-        tw.inverse(own, hand_mine, ln);
+        // (no favour() here: measured with it, NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms)
+        tw.inverse(own, hand_mine, ln, LaneNtt512::NoHook{});
         Part::sync();
 #pragma unroll
         for (int m = 0; m < E; m++) hand_mine[ln + 64u * m] = own[m];
@@ -584,6 +649,13 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     }
 }
 
+#ifdef FBS_CU_TRACE
+void cu_trace_dump(const char *kernel);
+#define FBS_TRACE_DUMP(k) cu_trace_dump(k)
+#else
+#define FBS_TRACE_DUMP(k)
+#endif
+
 bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
     if (ctx->group != 2 || !ctx->d_bsk_hat_small || p.log_n_poly != 11 || p.l_bsk > 2 || !ctx->tune.br_cu_kernel) return false;
@@ -620,11 +692,13 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
             if (lean) {                                                                          \
                 *kernel = "k_blind_rotate_cu<" #L "," #NL "," #FIRST ",lean>";                   \
                 hipLaunchKernelGGL((k_blind_rotate_cu<L, NL, FIRST, true>), grid, block, 0, stream, b); \
+                FBS_TRACE_DUMP(kernel->c_str());                                                 \
                 return true;                                                                     \
             }                                                                                    \
         }                                                                                        \
         *kernel = "k_blind_rotate_cu<" #L "," #NL "," #FIRST ">";                                \
         hipLaunchKernelGGL((k_blind_rotate_cu<L, NL, FIRST>), grid, block, 0, stream, b);        \
+        FBS_TRACE_DUMP(kernel->c_str());                                                         \
         return true;                                                                             \
     }
     CU_CASE(10, 1, 0) CU_CASE(10, 1, 1) CU_CASE(10, 1, 2)
@@ -636,6 +710,19 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
 #undef CU_CASE
     return false;
 }
+
+#ifdef FBS_CU_TRACE
+void cu_trace_dump(const char *kernel) {
+    unsigned long long h[8 * 16];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cu_trace), sizeof h) != hipSuccess) return;
+    fprintf(stderr, "trace %s (cycles per phase, workgroup 0, whole rotation):\n", kernel);
+    for (int w = 0; w < 8; w++) {
+        fprintf(stderr, "  wave %d:", w);
+        for (int k = 0; k < 12; k++) fprintf(stderr, " %9llu", h[w * 16 + k]);
+        fprintf(stderr, "\n");
+    }
+}
+#endif
 
 void blind_rotate_cu_catalog(std::vector<std::string> *out) {
     for (int nl = 1; nl <= 4; nl++)

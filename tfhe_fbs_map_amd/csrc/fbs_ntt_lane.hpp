@@ -180,7 +180,9 @@ struct LaneNtt256 {
         }
     }
     // evaluations (layout D, |x| < 2^52) -> 256 * coefficients of the part (layout A, |x| <= 8 q); `w` = load() of the INVERSE table
-    __device__ static __forceinline__ void inverse_one(double (&x)[E], double *buf, uint32_t ln, const Tw &w) {
+    // (`mid` runs half-way, between the two halves of the exchange)
+    template <class Hook = NoHook>
+    __device__ static __forceinline__ void inverse_one(double (&x)[E], double *buf, uint32_t ln, const Tw &w, Hook &&mid = NoHook{}) {
 #pragma unroll
         for (int m = 0; m < E; m++) x[m] = fp_center(x[m]);
         gs(x[0], x[1], w.t7a);
@@ -197,6 +199,7 @@ struct LaneNtt256 {
             sync();
 #pragma unroll
             for (int m = 0; m < E; m++) buf[wc ^ phys((uint32_t)m << 2)] = x[m];
+            mid();
             sync();
 #pragma unroll
             for (int m = 0; m < E; m++) x[m] = fp_center(buf[rb ^ phys((uint32_t)m << 4)]);
@@ -400,7 +403,9 @@ struct LaneNtt512 {
             for (int m = 0; m < 4; m++) ct(x[p][m], x[p][m + 4], w.t8[m]);                            // stage 8: bit 0 = r2, block (.., l5, r1, r0)
     }
     // evaluations (layout D, |x| < 2^52) -> 512 * coefficients of the part (layout A, |x| <= 4 q); inverse tables
-    __device__ static __forceinline__ void inverse_one(double (&x)[E], double *buf, uint32_t ln, const Uniform &u, const TwLane &w) {
+    template <class Hook = NoHook>
+    __device__ static __forceinline__ void inverse_one(double (&x)[E], double *buf, uint32_t ln, const Uniform &u, const TwLane &w,
+                                                       Hook &&mid = NoHook{}) {
 #pragma unroll
         for (int m = 0; m < E; m++) x[m] = fp_center(x[m]);
 #pragma unroll
@@ -420,6 +425,7 @@ struct LaneNtt512 {
             sync();
 #pragma unroll
             for (int m = 0; m < E; m++) buf[wc ^ phys(index_c(0, m))] = x[m];
+            mid();
             sync();
 #pragma unroll
             for (int m = 0; m < E; m++) x[m] = buf[rb ^ phys(index_b(0, m))];
