@@ -300,6 +300,10 @@ def roofline_record(prm, prof, kernels, B, steps):
                key_stream_vs_hbm_peak=br_bytes_per_fbs * units / (br_ms * 1e-3) / HBM_PEAK,
                key_stream_bytes_per_fbs=br_bytes_per_fbs,
                keyswitch_kernel=ks["kernel"], keyswitch_avg_launch_ms=ks_ms,
+               measured_issue_ceiling=dict(
+                   what="dependent v_fma_f64 chains (ILP 4-8) on every SIMD, tools/fp64_ilp.hip: one instruction per SIMD per 4.8-5.0 "
+                        "nominal cycles with two waves per SIMD (what 256-register kernels get), 4.7 with four -- not the nominal 4",
+                   frac_of_peak_two_waves_per_simd=[round(4 / 5.0, 2), round(4 / 4.8, 2)], source="profiles/r01/fp64_issue_rate.txt"),
                note="bound by FP64 VALU issue (one wave-instruction per SIMD per 4 cycles at the nominal 2.4 GHz); frac = algorithmic "
                     "work over time over that peak, valu_frac = executed instructions over the same (occupancy); "
                     "key_stream_vs_hbm_peak counts every key row once per bootstrap as SURVEY 8(d) prescribes and is not a utilisation: "
