@@ -543,6 +543,42 @@ def test_headline_shape_at_full_size_against_the_oracle(p1024_pair):
         assert np.array_equal(ctx.decrypt(got)[keep], np.array([tables[i][m] for i, m in zip(ids, msgs)])[keep])
 
 
+def test_config5_default_at_full_size_against_the_oracle(nat):
+    """BASELINE configs[4] as `LutExecEnv.eval` runs it by default: the 128-bit set for p = 31 (n = 766, N = 2048, two gadget
+    levels, two key bits per step) on k_blind_rotate_cu_pairs<11,2> -- 300 ciphertexts = a full round of whole-CU workgroups
+    and a second, partial one -- word for word against the oracle on both ends of both rounds, trivial ciphertexts included."""
+    import torch
+    from tfhe_fbs_map_amd import choose_params
+    prm = choose_params(31, 325)
+    assert (prm.N, prm.l_bsk, prm.bsk_group) == (2048, 2, 2), "the selector moved: pin this test's parameter set"
+    ctx, o = nat.Context(prm, seed=3), orc.Oracle(prm, seed=3)
+    rng = np.random.default_rng(11)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, 30)] for _ in range(4)] + [[int(v) for v in rng.integers(0, 31, 31)]]
+    tv = ctx.tvset(tables)
+    B, pick = 300, [0, 1, 2, 254, 255, 256, 257, 298, 299]
+    msgs = rng.integers(0, 31, B)
+    ids = (np.arange(B) % len(tables)).astype(np.uint32)
+    cts = ctx.encrypt(msgs, nonce0=100)
+    for i in (1, 256, B - 1):
+        cts[i, :-1] = 0                                              # trivial: every rotation amount zero
+    d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+    d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+    d_out = torch.empty_like(d_in)
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, d_out.data_ptr())
+    ctx.sync()
+    assert [k for k in ctx.profile_kernels() if "blind_rotate" in k] == ["k_blind_rotate_cu_pairs<11,2>"]
+    ctx.profile(False)
+    got = d_out.cpu().numpy().view(np.uint64)
+    ref, _ = o.bootstrap_batch(cts[pick], tables, ids[pick])
+    assert np.array_equal(got[pick], ref)
+    keep = np.ones(B, bool)
+    keep[[1, 256, B - 1]] = False
+    assert np.array_equal(ctx.decrypt(got)[keep], np.array([tables[i][m] for i, m in zip(ids, msgs)])[keep])
+    ctx.close()
+
+
 def test_imported_keys_give_the_oracles_ciphertexts(nat, toy_params):
     """fbs_import_keys: keys made elsewhere -- here by the oracle under ANOTHER seed -- instead of fbs_keygen.  The context then
     bootstraps exactly as the oracle does with those keys, and refuses keys that are not canonical."""
