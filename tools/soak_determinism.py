@@ -1,0 +1,41 @@
+"""Race hunt for the whole-CU kernels: every launch shape that shares LDS words between phases (hand-over = inverse exchange =
+re-deal in k_blind_rotate_cu_pairs; accumulator words = hand-over in k_blind_rotate_cu) is run REPS times on the same inputs at
+full n, with every CU busy, and every run must give the first run's ciphertexts bit for bit; the first run is checked against the
+expected cleartexts.  A race shows as a rare mismatch.   python3 tools/soak_determinism.py [reps = 40]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tfhe_fbs_map_amd import Context, P1024, choose_params
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+CASES = [("P1024", P1024, (64, 256, 300, 512)), ("p15 128-bit", choose_params(15, 70), (256, 200)),
+         ("p31 128-bit", choose_params(31, 325), (256, 300, 1024)), ("p31 one key bit", choose_params(31, 325, groups=(1,)), (256,)),
+         ("p4 128-bit", choose_params(4, 2), (256, 512))]
+bad = 0
+for label, prm, sizes in CASES:
+    ctx = Context(prm, seed=5)
+    p = prm.p_msg
+    rng = np.random.default_rng(9)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(8)]
+    tv = ctx.tvset(tables)
+    for B in sizes:
+        msgs = rng.integers(0, p, B)
+        ids = (np.arange(B) % 8).astype(np.uint32)
+        d_in = torch.from_numpy(ctx.encrypt(msgs, nonce0=1).view(np.int64)).cuda()
+        d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+        outs = [torch.empty_like(d_in) for _ in range(REPS)]
+        ctx.profile(True); ctx.profile_read(reset=True)
+        for o in outs:
+            ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, o.data_ptr())
+        ctx.sync()
+        kernels = [k for k in ctx.profile_kernels() if "blind_rotate" in k]
+        ctx.profile(False)
+        first = outs[0]
+        same = all(bool(torch.equal(first, o)) for o in outs[1:])
+        ok = np.array_equal(ctx.decrypt(first.cpu().numpy().view(np.uint64)), [tables[i][m] for i, m in zip(ids, msgs)])
+        bad += (not same) + (not ok)
+        print("%-16s B=%5d  %-50s  %d runs identical: %s   decrypts: %s" % (label, B, ",".join(kernels), REPS, same, ok), flush=True)
+    ctx.close()
+print("FAILED" if bad else "all deterministic")
+sys.exit(1 if bad else 0)
