@@ -459,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
 
     const uint32_t n_pairs = a.n / 2;
     uint32_t e0_next = ms[0], e1_next = ms[1];
+    FBS_TRACE_INIT
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
         e[0] = __builtin_amdgcn_readfirstlane(e0_next);
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
         if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the workgroup)
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
+        FBS_TRACE(0)
 
         // ---- what memory has to bring: psi^(e o_lane) for the three exponents, and the key words -----------------------------
         double A[3];
@@ -524,7 +526,9 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
                     for (int r = 0; r < EP; r++) region[q * M + t + (uint32_t)LANES * r] = x[lv][q * EP + r];
             }
         }
+        FBS_TRACE(1)
         __syncthreads();
+        FBS_TRACE(2)
         double *bufs[NL];
 #pragma unroll
         for (int lv = 0; lv < NL; lv++) {
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             for (int m = 0; m < E; m++) x[lv][m] = bufs[lv][ln + 64u * m];
         }
         tw.template forward<NL>(x, bufs, ln);
+        FBS_TRACE(3)
 
         // ---- the monomial factors ----------------------------------------------------------------------------------------
         // psi^(e o_lane) omega^s, s = 0 .. 3.  (Scalars, one set per exponent, on purpose: as one array indexed by the exponent's
@@ -599,15 +604,22 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         // ---- hand the partner its half, private inverse, re-deal back, the two joining stages, accumulate ------------------------
 #pragma unroll
         for (int m = 0; m < E; m++) hand_partner[64u * m + ln] = other[m];
+        FBS_TRACE(4)
         __syncthreads();
+        FBS_TRACE(5)
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
-        // (no favour() here: measured with it, NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms)
+        // (no favour() in this kernel.  Measured with it: NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms.
+        // The trace says why: the products are bound by the latency of the key loads, not by issue slots -- the wave that leads
+        // them takes 3.0 M cycles for 1.6 M cycles of instructions, the one that follows 5.4 M, whichever way the lead is given;
+        // starting the workgroups of an XCD a quarter of a step apart changes nothing either, so it is not their bursts meeting in L2.)
         tw.inverse(own, hand_mine, ln, LaneNtt512::NoHook{});
         Part::sync();
 #pragma unroll
         for (int m = 0; m < E; m++) hand_mine[ln + 64u * m] = own[m];
+        FBS_TRACE(6)
         __syncthreads();
+        FBS_TRACE(7)
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -627,7 +639,9 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
+        FBS_TRACE(8)
     }
+    FBS_TRACE_FLUSH
 
     if (!live) return;
     if (uint64_t *raw = gate_acc(a.gv, f, N)) {
@@ -664,9 +678,11 @@ bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t str
     if (p.l_bsk == 1) {
         *kernel = "k_blind_rotate_cu_pairs<11,1>";
         hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11, 1>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+        FBS_TRACE_DUMP(kernel->c_str());
     } else {
         *kernel = "k_blind_rotate_cu_pairs<11,2>";
         hipLaunchKernelGGL((k_blind_rotate_cu_pairs<11, 2>), dim3((unsigned)a.count), dim3(512), 0, stream, b);
+        FBS_TRACE_DUMP(kernel->c_str());
     }
     return true;
 }

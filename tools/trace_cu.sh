@@ -14,3 +14,10 @@ for V in 0 2; do
   echo "== FBS_CU_PRIO=$V, P1024, 64 bootstraps (waves 0-3: component 0, waves 4-7: component 1; wave w and w + 4 share a SIMD)"
   FBS_LIB=/tmp/libfbsexec_trace$V.so python3 bench.py --batch 64 --steps 2 --warmup 1 --cpu-sample 0 --no-secure 2>&1 >/dev/null | grep -A8 "^trace" | tail -9
 done
+# the two-key-bit kernels (no priority flips).  Columns: 0 loop top | 1 digits + cross stages + re-deal write | 2 WAIT re-deal barrier |
+#   3 forward transforms | 4 products (key words fetched pair by pair) + hand-over write | 5 WAIT hand-over barrier |
+#   6 hand-over read + inverse + write | 7 WAIT re-deal-back barrier | 8 join + accumulate
+echo "== k_blind_rotate_cu_pairs<11,2>: 128-bit set for p = 31, 64 bootstraps"
+FBS_LIB=/tmp/libfbsexec_trace2.so python3 tools/secure_bench.py 64 1 31 325 2>&1 | grep -A8 "^trace" | tail -9
+echo "== k_blind_rotate_cu_pairs<11,1>: 128-bit set for p = 15, 64 bootstraps"
+FBS_LIB=/tmp/libfbsexec_trace2.so python3 tools/secure_bench.py 64 1 15 70 2>&1 | grep -A8 "^trace" | tail -9
