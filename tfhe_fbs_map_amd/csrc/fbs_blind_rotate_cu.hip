@@ -610,9 +610,11 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
         // (no favour() in this kernel.  Measured with it: NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms.
-        // The trace says why: the products are bound by the latency of the key loads, not by issue slots -- the wave that leads
-        // them takes 3.0 M cycles for 1.6 M cycles of instructions, the one that follows 5.4 M, whichever way the lead is given;
-        // starting the workgroups of an XCD a quarter of a step apart changes nothing either, so it is not their bursts meeting in L2.)
+        // The trace shows the products phase far from issue-bound -- the wave that leads it takes 3.0 M cycles for 1.6 M cycles of
+        // instructions (NL = 2), the one that follows 5.4 M, whichever way the lead is given -- and two experiments say it is not
+        // the key loads either: starting the workgroups of an XCD a quarter of a step apart (their bursts would not meet in the L2)
+        // changes nothing, and requesting ALL key words at the top of the step (NL = 1: 96 registers, nothing spilled) is slower,
+        // 3.17 against 2.95 ms per 256 bootstraps.  Unexplained; the schedule below is the fastest of those measured.)
         tw.inverse(own, hand_mine, ln, LaneNtt512::NoHook{});
         Part::sync();
 #pragma unroll
