@@ -611,10 +611,14 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
         // (no favour() in this kernel.  Measured with it: NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms.
         // The trace shows the products phase far from issue-bound -- the wave that leads it takes 3.0 M cycles for 1.6 M cycles of
-        // instructions (NL = 2), the one that follows 5.4 M, whichever way the lead is given -- and two experiments say it is not
-        // the key loads either: starting the workgroups of an XCD a quarter of a step apart (their bursts would not meet in the L2)
-        // changes nothing, and requesting ALL key words at the top of the step (NL = 1: 96 registers, nothing spilled) is slower,
-        // 3.17 against 2.95 ms per 256 bootstraps.  Unexplained; the schedule below is the fastest of those measured.)
+        // instructions (NL = 2), the one that follows 5.4 M, whichever way the lead is given.  Its arithmetic alone runs at the
+        // FP64 issue ceiling (tools/products_bench.hip: 5.1-5.3 cycles per instruction at two waves per SIMD); what it waits for
+        // is the KEY ROW: every CU pulls the step's whole row out of L2 by itself (393 KB at NL = 2, 196 KB at NL = 1), a CU
+        // streams 90-120 GB/s from L2 at best (tools/l2_stream_bench.hip), and the loads come in this phase's third of the step.
+        // With half the distinct bytes (timing experiment) 4.62 -> 3.80 ms and 2.98 -> 2.63 ms per 256 bootstraps.  Requesting
+        // ALL key words at the top of the step is slower (NL = 1: 3.17 against 2.95 ms: the queue fills and blocks the wave at
+        // issue), non-temporal loads too, and starting the workgroups of an XCD a quarter of a step apart changes nothing
+        // (profiles/r03/microbench_products_l2.txt).)
         tw.inverse(own, hand_mine, ln, LaneNtt512::NoHook{});
         Part::sync();
 #pragma unroll
