@@ -92,7 +92,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
     constexpr int N = W::N, E = W::E, LANES = W::LANES;
     __shared__ double lds_all[FPW * 2 * 2 * N];   // [bootstrap][component][ping-pong][N]
     const uint32_t sub = threadIdx.x >> (LL + 1);          // which bootstrap of the workgroup
-    const uint32_t comp = (threadIdx.x >> LL) & 1u;        // GLWE component owned by this thread: 0 = mask, 1 = body
+    const uint32_t comp = __builtin_amdgcn_readfirstlane((threadIdx.x >> LL) & 1u);        // GLWE component owned by this thread: 0 = mask, 1 = body
     const uint32_t t = threadIdx.x & (LANES - 1);
     double *lds = lds_all + sub * (2 * 2 * N);
     double *mine = lds + comp * 2 * N;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
         sign_bits |= bhalf << (j * a.beta);
     }
 
+    const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     uint32_t r_next = ms[0];   // the rotation amount of a step is fetched one step ahead: its latency is never exposed
     constexpr int PRIO = !TURNS ? 0 : LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
     const uint32_t slot = PRIO ? wave_slot_parity() : 0u;
@@ -204,9 +205,10 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int m = 0; m < E; m++)
                 x[m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);   // balanced digit in [-B/2, B/2)
-            const double *krow = a.bsk_hat + (((size_t)i * rows + comp * a.l + lv) * 2) * N;
-            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
-            const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+            // (buffer loads, KeyRows: the step's rows behind one resource, the polynomial picked by a scalar byte offset)
+            const KeyRows keys(a.bsk_hat + (size_t)i * rows * 2 * N);
+            const uint32_t krow = ((comp * a.l + (uint32_t)lv) * 2u) * (uint32_t)(N * 8);
+            const uint32_t k_own = krow + comp * (uint32_t)(N * 8), k_oth = krow + (comp ^ 1u) * (uint32_t)(N * 8);
             // The first half of the "own" key polynomial is requested before the last butterfly group of the transform
             // (one group ~ one L2 round trip), the rest after it.  Measured on MI355X: 13.5 -> 12.8 ms per 1024-batch;
             // asking for more ahead of time (all of it, or the partner's polynomial too) spills and loses again.
@@ -214,10 +216,10 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             double2 ko[E / 2];
             W::template forward<FIRST>(x, xc, t, twf, [&] {
 #pragma unroll
-                for (int m = 0; m < EARLY; m++) ko[m] = k_own[m * LANES + t];
+                for (int m = 0; m < EARLY; m++) ko[m] = keys.load(t16 + (uint32_t)(m * LANES * 16), k_own);
             });
 #pragma unroll
-            for (int m = EARLY; m < E / 2; m++) ko[m] = k_own[m * LANES + t];
+            for (int m = EARLY; m < E / 2; m++) ko[m] = keys.load(t16 + (uint32_t)(m * LANES * 16), k_own);
             // own products first; each finished pair frees the registers its key words sat in, and the partner's
             // key words are requested into them while the remaining own products run
             double2 kt[E / 2];
@@ -226,7 +228,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
                 const double p0 = fp_mulmod(x[2 * j], ko[j].x), p1 = fp_mulmod(x[2 * j + 1], ko[j].y);
                 own[2 * j] = ASSIGN ? p0 : own[2 * j] + p0;
                 own[2 * j + 1] = ASSIGN ? p1 : own[2 * j + 1] + p1;
-                kt[j] = k_oth[j * LANES + t];
+                kt[j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_oth);
             }
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     // walk the banks with stride e (two-way for odd e, which a 64-lane 8-byte read is anyway; at worst eight-way).
     __shared__ __attribute__((aligned(16384))) double lds_all[2 * 2 * N + N];
     constexpr int GLOG = W::EVAL_GROUP_LOG2, G = 1 << GLOG;
-    const uint32_t comp = (threadIdx.x >> LL) & 1u;
+    const uint32_t comp = __builtin_amdgcn_readfirstlane((threadIdx.x >> LL) & 1u);
     const uint32_t t = threadIdx.x & (LANES - 1);
     double *lds = lds_all;
     double *mine = lds + comp * 2 * N;
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     constexpr uint32_t MASK8 = (uint32_t)(N / G - 1) << 3;
     const uint32_t psi_base = (uint32_t)(uintptr_t)(lds + 4 * N);   // LDS byte address of the table (16 KB aligned)
 
+    const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     const uint32_t n_pairs = a.n / 2;
     uint32_t e0_next = ms[0], e1_next = ms[1];
     constexpr int PRIO = LL <= 6 ? FBS_PRIO_ONE_WAVE : FBS_PRIO_MULTI_WAVE;
@@ -413,12 +416,15 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             // used, level by level, instead of being hoisted out of the level loop into more SGPRs than there are)
             uint32_t e_lv[3] = {e[0], e[1], e[2]};
             if constexpr (!ONE_LEVEL) asm volatile("" : "+s"(e_lv[0]), "+s"(e_lv[1]), "+s"(e_lv[2]));
-            const double2 *k_own[3], *k_oth[3];
+            // the step's key rows (three samples of `rows` rows of two polynomials) behind one buffer resource; own / partner's
+            // polynomial of this component's row of sample jj: scalar byte offsets
+            const KeyRows keys(a.bsk_hat + (size_t)i * 3 * rows * 2 * N);
+            uint32_t k_own[3], k_oth[3];
 #pragma unroll
             for (int jj = 0; jj < 3; jj++) {
-                const double *krow = a.bsk_hat + ((((size_t)i * 3 + jj) * rows + comp * a.l + lv) * 2) * N;
-                k_own[jj] = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
-                k_oth[jj] = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+                const uint32_t krow = (((uint32_t)jj * rows + comp * a.l + (uint32_t)lv) * 2u) * (uint32_t)(N * 8);
+                k_own[jj] = krow + comp * (uint32_t)(N * 8);
+                k_oth[jj] = krow + (comp ^ 1u) * (uint32_t)(N * 8);
             }
             // what one register pair (2j, 2j+1) needs from memory: its words of the six key polynomials ...
             struct PairKeys {
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
                 constexpr int j = decltype(jc)::value;
 #pragma unroll
                 for (int jj = 0; jj < 3; jj++) {
-                    in.ko[jj] = k_own[jj][j * LANES + t];
-                    in.kt[jj] = k_oth[jj][j * LANES + t];
+                    in.ko[jj] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_own[jj]);
+                    in.kt[jj] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_oth[jj]);
                 }
             };
             auto consume = [&](auto jc, const PairKeys &in) {
@@ -459,9 +465,11 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
                 // key words of the bundle: lazy sums of three exact products (< 2.3 q).  With |x| < 2^49.3 (general first
                 // stage) the product below stays within 0.9 q as it is; the two-FMA first stage leaves |x| near 2^51 and
                 // wants the word centred first.
-                double wo0 = 0, wo1 = 0, wt0 = 0, wt1 = 0;
+                // (the first product initialises the sums: 0.0 + x is an instruction the compiler may not drop, -0.0 being a double)
+                double wo0 = fp_mulmod(in.ko[0].x, mono[0][0]), wo1 = fp_mulmod(in.ko[0].y, mono[0][1]);
+                double wt0 = fp_mulmod(in.kt[0].x, mono[0][0]), wt1 = fp_mulmod(in.kt[0].y, mono[0][1]);
 #pragma unroll
-                for (int jj = 0; jj < 3; jj++) {
+                for (int jj = 1; jj < 3; jj++) {
                     wo0 += fp_mulmod(in.ko[jj].x, mono[jj][0]);
                     wo1 += fp_mulmod(in.ko[jj].y, mono[jj][1]);
                     wt0 += fp_mulmod(in.kt[jj].x, mono[jj][0]);
@@ -485,6 +493,8 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             PairKeys in;
             W::template forward<FIRST>(x, xc, t, twf, [&] { request(std::integral_constant<int, 0>{}, in); });
             static_assert(E == 16, "eight register pairs, written out");
+            // (round 3, with the buffer loads' forty spare registers: pair j + 1 requested before pair j is consumed -- 9.21 against 9.23 ms
+            // per 1024 bootstraps at the 128-bit p = 15 set, i.e. nothing: left as it was)
 #define FBS_PAIR_STEP(J)                                                                                    \
     if constexpr ((J) > 0) request(std::integral_constant<int, (J)>{}, in);                                 \
     consume(std::integral_constant<int, (J)>{}, in);                                                        \

@@ -51,6 +51,26 @@ __device__ __forceinline__ void lead_if(uint32_t turn, uint32_t slot) {
     }
 }
 
+// Key words through BUFFER loads.  The resource (base address of the step's key rows, four SGPRs) and the distance to the
+// polynomial wanted (one SGPR) are wave-uniform; every thread supplies ONE 32-bit byte offset, and register pairs further along the
+// polynomial are reached through the instruction's immediate offset -- no 64-bit address arithmetic on the vector pipe and no
+// register pair per address (flat global loads: 78 of the 2 873 vector instructions of a k_blind_rotate_pairs<11,7,4> step and
+// more than thirty registers went into addresses).  `base` must be wave-uniform.
+struct KeyRows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit KeyRows(const double *base)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base), 0, 0x7FFFFFFF, 0x00020000)) {}
+    // 16 bytes at base + poly_bytes + thread_bytes (+ the immediate the compiler splits off thread_bytes' constant part)
+    __device__ __forceinline__ double2 load(uint32_t thread_bytes, uint32_t poly_bytes) const {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, thread_bytes, poly_bytes, 0);
+        double2 r;
+        r.x = __hiloint2double((int)v.y, (int)v.x);
+        r.y = __hiloint2double((int)v.w, (int)v.z);
+        return r;
+    }
+};
+
 // fbs_blind_rotate_cu.hip: one bootstrap on the eight waves of a CU (N = 1024, at most four gadget levels).  Returns false when
 // there is no instantiation for the context's parameters (the caller then takes the generic kernel); *kernel = its name.
 bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);

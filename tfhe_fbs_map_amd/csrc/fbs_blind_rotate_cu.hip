@@ -153,7 +153,8 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     // [2][NL][N] re-deal + private exchange buffers of the forward transforms (level 0's doubles for the inverse); the
     // inverse per-lane twiddles of 512-point parts.  64 KB at N = 1024, NL = 3; 130 KB at N = 2048, NL = 2.
     __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part, LEAN>::LDS_WORDS];
-    const uint32_t comp = threadIdx.x >> 8;          // GLWE component owned by this thread: 0 = mask, 1 = body
+    // GLWE component owned by this thread: 0 = mask, 1 = body (wave-uniform, and known to the compiler as such)
+    const uint32_t comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
     const uint32_t t = threadIdx.x & (LANES - 1);    // thread of the component
     const uint32_t w = W::wave_of(t), ln = t & 63u;  // which part this wave owns; lane
     double *accbuf = lds_all + comp * N;
@@ -202,8 +203,9 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     for (int m = 0; m < E; m++) accbuf[t + (uint32_t)LANES * m] = acc[m];
     __syncthreads();
 
+    const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     uint32_t r_next = ms[0];
-    const bool second = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0u;   // this wave belongs to component 1 (scalar)
+    const bool second = comp != 0u;   // this wave belongs to component 1 (scalar)
     FBS_TRACE_INIT
     for (uint32_t i = 0; i < a.n; i++) {
         const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
@@ -214,15 +216,14 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
         // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
         // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
         double2 ko[NL][E / 2], kt[NL][E / 2];
+        const KeyRows keys(a.bsk_hat + ((size_t)i * rows + comp * NL) * 2 * N);   // (buffer loads: fbs_blind_rotate.hpp)
 #pragma unroll
         for (int lv = 0; lv < NL; lv++) {
-            const double *krow = a.bsk_hat + (((size_t)i * rows + comp * NL + lv) * 2) * N;
-            const double2 *k_own = reinterpret_cast<const double2 *>(krow + (size_t)comp * N);
-            const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+            const uint32_t k_own = ((uint32_t)lv * 2u + comp) * (uint32_t)(N * 8), k_oth = ((uint32_t)lv * 2u + (comp ^ 1u)) * (uint32_t)(N * 8);
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
-                ko[lv][j] = k_own[j * LANES + t];
-                if constexpr (!LEAN) kt[lv][j] = k_oth[j * LANES + t];
+                ko[lv][j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_own);
+                if constexpr (!LEAN) kt[lv][j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_oth);
             }
         }
 
@@ -281,10 +282,9 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
         if constexpr (LEAN) {   // what the forward transforms had no registers for
 #pragma unroll
             for (int lv = 0; lv < NL; lv++) {
-                const double *krow = a.bsk_hat + (((size_t)i * rows + comp * NL + lv) * 2) * N;
-                const double2 *k_oth = reinterpret_cast<const double2 *>(krow + (size_t)(comp ^ 1u) * N);
+                const uint32_t k_oth = ((uint32_t)lv * 2u + (comp ^ 1u)) * (uint32_t)(N * 8);
 #pragma unroll
-                for (int j = 0; j < E / 2; j++) kt[lv][j] = k_oth[j * LANES + t];
+                for (int j = 0; j < E / 2; j++) kt[lv][j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_oth);
             }
             tw.prefetch_inverse();
         }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     // barrier beyond the two they have (the next step's hand-over lies behind that step's re-deal barrier); [2][NL][N] re-deal +
     // private exchange of the forward transforms; the inverse per-lane twiddles.  100 KB (NL = 1), 133 KB (NL = 2).
     __shared__ double lds_all[2 * N + 2 * NL * N + CuTwiddles<Part, false>::LDS_WORDS];
-    const uint32_t comp = threadIdx.x >> 8, t = threadIdx.x & (LANES - 1);
+    const uint32_t comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & (LANES - 1);
     const uint32_t w = W::wave_of(t), ln = t & 63u;
     double *back = lds_all + comp * N;
     double *hand_mine = back + w * M, *hand_partner = lds_all + (comp ^ 1u) * N + w * M;
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     const double om1 = psi_u[512], om2 = psi_u[1024], om3 = psi_u[1536];
     __syncthreads();   // (the inverse twiddle table is in place)
 
+    const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     const uint32_t n_pairs = a.n / 2;
     uint32_t e0_next = ms[0], e1_next = ms[1];
     FBS_TRACE_INIT
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));   // psi^(x + N) = -psi^x
         }
         // row (jj, comp NL + lv) of step i: its own column (this component's products) and the partner's
-        const double *kstep = a.bsk_hat + (size_t)i * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N;
+        const KeyRows keys(a.bsk_hat + (size_t)i * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N);   // (buffer loads: fbs_blind_rotate.hpp)
         // (the key words of one register pair (2j, 2j + 1): three samples x NL rows, of the own or of the partner's column)
         auto request = [&](auto jc, auto partner, double2 (&k)[3][NL]) {
             constexpr int j = decltype(jc)::value;
@@ -488,13 +489,16 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             for (int jj = 0; jj < 3; jj++)
 #pragma unroll
                 for (int lv = 0; lv < NL; lv++)
-                    k[jj][lv] = reinterpret_cast<const double2 *>(kstep + ((size_t)(jj * (int)rows + lv) * 2u + col) * N)[j * LANES + t];
+                    k[jj][lv] = keys.load(t16 + (uint32_t)(j * LANES * 16), ((uint32_t)(jj * (int)rows + lv) * 2u + col) * (uint32_t)(N * 8));
         };
         using Own = std::false_type;
         using Oth = std::true_type;
         // Pair 0's words are requested here, ahead of the transforms; pair j + 1's when pair j has been used up.  Measured against
         // holding more through the transforms (NL = 1: all own words, 3.09 ms per 256 bootstraps against 2.89; NL = 2: two pairs,
         // 17.7 against 17.1 ms per 1024): what counts is that nothing is spilled.
+        // (With the buffer loads' spare registers -- 196 at NL = 2 -- a second set of key words fits: pair j + 1 requested BEFORE pair j is
+        // consumed.  Measured, same box, twice each: NL = 1 2.76-2.79 against 2.79-2.85 ms per 256 bootstraps, NL = 2 16.72-16.74
+        // against 16.55 ms per 1024 -- within the noise one way, 1 % the other: not adopted.)
         double2 ko[3][NL], kt[3][NL];
         request(std::integral_constant<int, 0>{}, Own{}, ko);
         request(std::integral_constant<int, 0>{}, Oth{}, kt);
@@ -576,9 +580,10 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
                 const double mo[3] = {mono(V0, e[0], m), mono(V1, e[1], m), mono(V2, e[2], m)};
 #pragma unroll
                 for (int lv = 0; lv < NL; lv++) {
-                    double wo = 0.0, wt = 0.0;
+                    // (the first product initialises the sums: 0.0 + x is an instruction the compiler may not drop)
+                    double wo = fp_mulmod(r ? k_own[0][lv].y : k_own[0][lv].x, mo[0]), wt = fp_mulmod(r ? k_oth[0][lv].y : k_oth[0][lv].x, mo[0]);
 #pragma unroll
-                    for (int jj = 0; jj < 3; jj++) {
+                    for (int jj = 1; jj < 3; jj++) {
                         const double2 a_own = k_own[jj][lv], a_oth = k_oth[jj][lv];
                         wo += fp_mulmod(r ? a_own.y : a_own.x, mo[jj]);
                         wt += fp_mulmod(r ? a_oth.y : a_oth.x, mo[jj]);
