@@ -331,6 +331,11 @@ def roofline_record(prm, prof, kernels, B, steps):
         rec["traffic"] = pmc.get("hbm_bytes_per_launch")          # bytes per launch, FETCH_SIZE x2 + WRITE_SIZE
         if rec["traffic"]:
             rec["fabric_GBps"] = rec["traffic"] / (br_ms * 1e-3) / 1e9
+        # the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/r03/kernel_stats_*.csv): this kernel's
+        # duration there, beside the live avg_launch_ms (under the tracer a launch runs 1-4 % longer; its minimum is the live time)
+        if pmc.get("rocprof_avg_launch_ms") is not None:
+            rec["rocprof_kernel_trace_ms"] = dict(avg=pmc["rocprof_avg_launch_ms"], min=pmc.get("rocprof_min_launch_ms"),
+                                                  live_over_avg=br_ms / pmc["rocprof_avg_launch_ms"])
         rec["pmc"] = "%s; collected offline in separate rocprofv3 --pmc passes of this command on these kernel sources, not in this run" % pmc.get("source")
         rec["traffic_source"] = rec["pmc"]
     return rec
