@@ -109,7 +109,10 @@ def test_lincomb_and_stages(toy):
 
 @pytest.mark.parametrize("name,T", [("demo_fbs_exec_env", 2), ("edge_outputs", 6), ("edge_nomerge", 6),
                                     ("full_adder__search_p7", 8), ("aoi21__naive_p7", 8), ("adder8__search_p7", 3),
-                                    ("ascon_lut__search_p7", 2)])
+                                    ("ascon_lut__search_p7", 2),
+                                    # the BASELINE circuits' stand-ins on the CPU path (configs[0]: "CPU FBS, plumbing, no GPU";
+                                    # configs[2]; configs[4] = fbs_size 31), whole programs at toy n
+                                    ("adder128__search_p15", 2), ("mul16__search_p15", 1), ("adder128__search_p31", 1)])
 @pytest.mark.parametrize("group", [1, 2])
 def test_homomorphic_program_matches_reference_golden(toy_params, name, T, group):
     """The decrypted level is what pins the encrypted path to the reference: with one key bit per blind-rotation step and
