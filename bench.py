@@ -40,7 +40,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8.0 TB/s spec
 CLOCK_HZ = 2.4e9           # nominal engine clock
 SIMDS = 256 * 4            # 256 CUs x 4 SIMDs, one FP64 VALU wave-instruction per SIMD per 4 cycles
-PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_blind_rotate.json")   # counters of the timed kernel, collected offline
+
+
+def _latest_pmc_file():
+    """Counters of the timed kernels, collected offline (tools/profile_round.sh + collect_profiles.sh): the newest round's record."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_blind_rotate.json")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r03", "pmc_blind_rotate.json")
+
+
+PMC_FILE = _latest_pmc_file()
 BUTTERFLY_INSTR = 8        # exact 46-bit modular butterfly on the FP64 pipe: 6-instruction product, one add, one subtract
 MAC_INSTR = 7              # exact product + lazy accumulate
 
