@@ -162,11 +162,11 @@ def _all_gather_rows(out, send, world, group):
 # how to cut a program over G ranks
 # --------------------------------------------------------------------------------------------
 # One key switch + blind rotation launch of `count` bootstraps on one MI355X at the benchmark shape P1024, in ms
-# (profiles/r03/batch_sweep.txt).  Up to one bootstrap per CU a launch costs the latency of one bootstrap on a whole CU
+# (profiles/r03/batch_sweep.txt, the buffer-load kernels).  Up to one bootstrap per CU a launch costs the latency of one bootstrap on a whole CU
 # (k_blind_rotate_cu), up to two that of two workgroups sharing a CU, then the small workgroups, then whole rounds of four per
 # CU; beyond a round, rounds + remainder.
-LAUNCH_MS_P1024 = ((1, 2.93), (128, 2.99), (256, 3.24), (257, 5.60), (512, 5.56), (513, 8.20), (768, 8.37), (769, 9.30), (1024, 9.50))
-ROUND_MS_P1024 = 9.30      # per further round of 1024 in a long launch (8192 bootstraps: 73.2 ms)
+LAUNCH_MS_P1024 = ((1, 2.91), (128, 2.92), (256, 3.14), (257, 5.46), (512, 5.53), (513, 8.21), (768, 8.21), (769, 9.29), (1024, 9.29))
+ROUND_MS_P1024 = 9.20      # per further round of 1024 in a long launch (8192 bootstraps: 73.8 ms)
 
 
 def launch_ms(count, cost=1.0):
