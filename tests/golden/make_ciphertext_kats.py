@@ -41,6 +41,13 @@ SETS = {
     "secure_p4_n1024": dict(n=638, log_n_poly=10, k=1, l_bsk=2, beta_bsk=8, t_ksk=12, gamma_ksk=1, p_msg=4, sigma_lwe=4328098537,
                             sigma_glwe=3511592, bsk_group=1),
 }
+# Frozen AHEAD of the kernels (held by the CPU test only; the library refuses k != 1 today): GLWE dimension k = 2 at N = 1024 with
+# two key bits per step -- what DESIGN.md section 8 names as the next kernel for the 128-bit p = 15 default (n = 760 and a 16-bit
+# key switch for 6.7 sigma at norm2 70 by params.variances).  The oracle is written for any k; this pins what it computes there.
+SETS_AHEAD = {
+    "secure_p15_k2_n1024_two_key_bits_per_step": dict(n=760, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=8, gamma_ksk=2, p_msg=15,
+                                                      sigma_lwe=456472211, sigma_glwe=4, bsk_group=2),
+}
 SEED = 1
 COUNT = 5
 
@@ -87,9 +94,11 @@ def fused_case():
 def main():
     kats = {name: batch_case(name, prm) for name, prm in SETS.items()}
     kats["fused_adder8"] = fused_case()
+    ahead = {name: batch_case(name, prm) for name, prm in SETS_AHEAD.items()}
     with open(OUT, "w") as f:
         json.dump(dict(modulus=int(orc.Q), note="written by tests/golden/make_ciphertext_kats.py from oracle/tfhe_oracle.c; "
-                                                "see its docstring before changing this file", kats=kats), f, indent=1, sort_keys=True)
+                                                "see its docstring before changing this file", kats=kats,
+                       kats_ahead_of_the_kernels=ahead), f, indent=1, sort_keys=True)
         f.write("\n")
     print("wrote", OUT)
 

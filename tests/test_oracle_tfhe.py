@@ -263,6 +263,12 @@ def test_ciphertext_kats():
         got = mod.batch_case(name, prm)
         assert got == want["kats"][name], name
     assert mod.fused_case() == want["kats"]["fused_adder8"]
+    # sets frozen ahead of their kernels (k = 2: the oracle is general in k, the library is not yet)
+    assert set(want["kats_ahead_of_the_kernels"]) == set(mod.SETS_AHEAD)
+    for name, prm in mod.SETS_AHEAD.items():
+        got = mod.batch_case(name, prm)
+        assert got == want["kats_ahead_of_the_kernels"][name], name
+        assert got["decrypts_to"] == [got["tables"][i][m] for i, m in zip(got["table_ids"], got["msgs"])][:-1] + got["decrypts_to"][-1:]
 
 
 def test_tuned_baseline_equals_the_oracle():
