@@ -690,6 +690,16 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
+    if (p.k == 2) {   // GLWE dimension 2 (N = 1024, two key bits per step, one level: dev_supported admits nothing else)
+        if (gv.acc_rows || gv.row_words) return set_error(ctx, FBS_E_INVALID, "shared rotations are built for k = 1");
+        a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
+        hipEvent_t c0, c1;
+        prof_begin(ctx, 1, stream, &c0, &c1);
+        if (!launch_blind_rotate_k2(ctx, a, stream, &ctx->prof.kernel[1])) return set_error(ctx, FBS_E_INVALID, "no blind-rotation kernel for this k = 2 shape");
+        prof_end(ctx, 1, stream, c0, c1);
+        FBS_HIP(ctx, hipGetLastError());
+        return FBS_OK;
+    }
     if (ctx->group == 2) {
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
         // launches of at most one bootstrap per CU: the whole-CU shape (2.65-2.9 ms per bootstrap against 3.3-3.4; two rounds of
@@ -841,6 +851,7 @@ void blind_rotate_catalog(std::vector<std::string> *out) {
         for (int dig : {0, 3, 4})
             out->push_back("k_blind_rotate_pairs<" + std::to_string(L) + "," + std::to_string(lanes_log2_for(L)) + "," + std::to_string(dig) + ">");
     blind_rotate_cu_catalog(out);
+    blind_rotate_k2_catalog(out);
 }
 
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream) {

@@ -77,5 +77,9 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
 // ... with two key bits per step (N = 2048, one gadget level)
 bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_cu_catalog(std::vector<std::string> *out);
+// fbs_blind_rotate_k2.hip: GLWE dimension k = 2 at N = 1024 (two key bits per step, one gadget level): three waves per bootstrap,
+// four bootstraps per workgroup.  Returns false when the context is not of that shape.
+bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
+void blind_rotate_k2_catalog(std::vector<std::string> *out);
 
 }  // namespace fbs

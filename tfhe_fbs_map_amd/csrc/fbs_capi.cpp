@@ -651,6 +651,7 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
     if (!d || !out) return set_error(ctx, FBS_E_INVALID, "null argument");
     *out = nullptr;
     if (flags & ~(uint32_t)FBS_LOAD_FUSE_TABLES) return set_error(ctx, FBS_E_INVALID, "unknown load flag");
+    if ((flags & FBS_LOAD_FUSE_TABLES) && ctx->p.k != 1) return set_error(ctx, FBS_E_INVALID, "shared rotations (FBS_LOAD_FUSE_TABLES) are built for k = 1");
     std::unique_ptr<fbs_prog, void (*)(fbs_prog *)> prog(new fbs_prog, fbs_program_destroy);
     prog->fused = (flags & FBS_LOAD_FUSE_TABLES) != 0;
     prog->ctx = ctx;

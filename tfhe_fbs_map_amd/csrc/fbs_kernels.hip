@@ -648,7 +648,9 @@ void prof_end(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t e0, hipEvent_t 
 
 int dev_supported(const fbs_ctx *ctx) {
     const fbs_params &p = ctx->p;
-    if (p.k != 1) return set_error(ctx, FBS_E_INVALID, "this build supports GLWE dimension k = 1 only");
+    if (p.k == 2 && !(p.log_n_poly == 10 && p.bsk_group == 2 && p.l_bsk == 1))
+        return set_error(ctx, FBS_E_INVALID, "GLWE dimension k = 2 is built for N = 1024 with two key bits per step and one gadget level");
+    if (p.k != 1 && p.k != 2) return set_error(ctx, FBS_E_INVALID, "this build supports GLWE dimensions k = 1 and k = 2 (N = 1024) only");
     if (p.log_n_poly < 8 || p.log_n_poly > 12)
         return set_error(ctx, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048, 4096");
     if (p.l_bsk < 1 || p.beta_bsk < 1 || p.l_bsk * p.beta_bsk > 30 || p.l_bsk * p.beta_bsk > FQ_BITS - 2)
