@@ -38,16 +38,15 @@ SETS = {
     # (round 3: what the selector returns for (31, 325) since two key bits per step with two gadget levels have their kernel)
     "secure_p31_two_key_bits_per_step": dict(n=766, log_n_poly=11, k=1, l_bsk=2, beta_bsk=14, t_ksk=8, gamma_ksk=2, p_msg=31,
                                              sigma_lwe=408668278, sigma_glwe=4, bsk_group=2),
+    # (round 3) GLWE dimension k = 2 at N = 1024, two key bits per step (k_blind_rotate_pairs_k2): n = 760 and a 16-bit key switch
+    # give p = 15 at norm2 70 6.7 sigma by params.variances.  Frozen from the oracle (general in k) before the kernel existed.
+    "secure_p15_k2_n1024_two_key_bits_per_step": dict(n=760, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=8, gamma_ksk=2, p_msg=15,
+                                                      sigma_lwe=456472211, sigma_glwe=4, bsk_group=2),
     "secure_p4_n1024": dict(n=638, log_n_poly=10, k=1, l_bsk=2, beta_bsk=8, t_ksk=12, gamma_ksk=1, p_msg=4, sigma_lwe=4328098537,
                             sigma_glwe=3511592, bsk_group=1),
 }
-# Frozen AHEAD of the kernels (held by the CPU test only; the library refuses k != 1 today): GLWE dimension k = 2 at N = 1024 with
-# two key bits per step -- what DESIGN.md section 8 names as the next kernel for the 128-bit p = 15 default (n = 760 and a 16-bit
-# key switch for 6.7 sigma at norm2 70 by params.variances).  The oracle is written for any k; this pins what it computes there.
-SETS_AHEAD = {
-    "secure_p15_k2_n1024_two_key_bits_per_step": dict(n=760, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=8, gamma_ksk=2, p_msg=15,
-                                                      sigma_lwe=456472211, sigma_glwe=4, bsk_group=2),
-}
+# sets frozen AHEAD of their kernels would go here (held by the CPU test only); none at present
+SETS_AHEAD = {}
 SEED = 1
 COUNT = 5
 

@@ -55,6 +55,8 @@ def recipe(name):
         return dict(log_n=11, l=1, beta=20, group=2, count=CUS - 9, knobs={})
     if name == "k_blind_rotate_cu_pairs<11,2>":           # ... with two gadget levels: every launch, round after round
         return dict(log_n=11, l=2, beta=10, group=2, count=CUS + 21, knobs={})
+    if name == "k_blind_rotate_pairs_k2<10>":             # GLWE dimension k = 2: four bootstraps per workgroup, a ragged last one
+        return dict(log_n=10, l=1, beta=20, group=2, k=2, count=CUS + 41, knobs={})
     m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))
@@ -86,7 +88,7 @@ def pytest_generate_tests(metafunc):
 def run_case(name, rec):
     from tfhe_fbs_map_amd import Params, _native as nat
     n = 8 if rec["log_n"] < 12 else 4
-    prm = Params(n=n, log_n_poly=rec["log_n"], l_bsk=rec["l"], beta_bsk=rec["beta"], t_ksk=4, gamma_ksk=4 if rec["log_n"] < 12 else 3, p_msg=7,
+    prm = Params(n=n, log_n_poly=rec["log_n"], k=rec.get("k", 1), l_bsk=rec["l"], beta_bsk=rec["beta"], t_ksk=4, gamma_ksk=4 if rec["log_n"] < 12 else 3, p_msg=7,
                  sigma_lwe=1 << 6, sigma_glwe=1 << 4, bsk_group=rec["group"])
     ctx, o = nat.Context(prm, seed=21), orc.Oracle(prm, seed=21)
     ctx.tune(**rec["knobs"])

@@ -127,3 +127,18 @@ def test_exec_estimate_is_the_references_total_cost_in_this_executors_unit():
     # more plaintext bits per bootstrap cost more per bootstrap (the reference's 40 / 47 / 69 / 75 points have the same order)
     costs = [exec_estimate(p, 59, 1)["boot_cost"] for p in (4, 9, 17, 31)]
     assert costs == sorted(costs)
+
+
+def test_glwe_dimension_two_is_an_option_not_the_default():
+    """k = 2 (N = 1024, two key bits per step, one level: what k_blind_rotate_pairs_k2 is built for) is returned only when asked
+    for, where it is cheaper and reaches the margin; ExecConfig asks for it by the program's bootstraps per level x samples."""
+    from tfhe_fbs_map_amd import ExecConfig
+    from tfhe_fbs_map_amd.params import bootstrap_cost, choose_params, margin_sigmas, security_bits
+    a, b = choose_params(15, 70), choose_params(15, 70, glwe_dims=(1, 2))
+    assert a.k == 1 and b.k == 2 and (b.N, b.l_bsk, b.bsk_group) == (1024, 1, 2)
+    assert bootstrap_cost(b) < 0.85 * bootstrap_cost(a) and margin_sigmas(b, 70) >= 6.0 and security_bits(b) >= 127.9
+    assert choose_params(31, 325, glwe_dims=(1, 2)).k == 1          # p = 31 does not fit 2N = 2048 slots at 6 sigma
+    assert choose_params(15, 70, glwe_dims=(1, 2), groups=(1,)).k == 1
+    cfg = ExecConfig(seed=1)
+    assert cfg.params_choice(15, 70).k == 1 and cfg.params_choice(15, 70, wide=True).k == 2
+    assert ExecConfig(seed=1, glwe_dims=(1,)).params_choice(15, 70, wide=True).k == 1

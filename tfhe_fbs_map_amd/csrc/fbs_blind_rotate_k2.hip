@@ -4,7 +4,8 @@
 // transform (the structure of the benchmark kernel k_blind_rotate<10,6,3,4>, which issues 0.79-0.80 of the FP64 peak where the
 // two-waves-per-polynomial kernels issue 0.69-0.71).  gfx950 only; the algebra is k_blind_rotate_pairs' (fbs_blind_rotate.hip):
 //     ACC += [ (X^a0 - 1) E0 + (X^a1 - 1) E1 + (X^(a0+a1) - 1) E2 ]  (x)  ACC
-// with the bundle built in the transform domain and ACC itself decomposed; same rounding rules, same ciphertexts as the oracle.
+// with the bundle built in the transform domain and ACC itself decomposed; same rounding rules and, word for word, the same
+// ciphertexts as the k = 1 kernels' conventions give at k = 2 (tests/test_gpu_k2.py).
 //
 // One bootstrap = three waves (component c = wave c of the bootstrap: two mask polynomials and the body).  Three does not divide
 // the eight 256-register waves a CU holds, so the kernel is written for THREE waves per SIMD: 168 registers, twelve waves = four

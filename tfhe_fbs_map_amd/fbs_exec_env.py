@@ -113,6 +113,12 @@ class ExecConfig:
     # times the noise variance, so the parameter set is chosen for the program's FUSED norm and its cost times the rotations
     # left is compared with the unfused choice.  With explicit `params` None means off (their margin is the caller's).
     fuse_tables: bool | None = None
+    # GLWE dimensions the selector may use.  k = 2 (N = 1024, two key bits per step: k_blind_rotate_pairs_k2) is 0.81 of the k = 1
+    # sets' cost per bootstrap in launches of a round (1 024 bootstraps) or more, but takes a whole round's 7 ms for a launch of any
+    # size where the k = 1 sets have their one-bootstrap-per-CU kernels: `choose` admits it for programs whose levels average
+    # `wide_level` bootstraps (gates of the level x samples) or more, and only without shared rotations (built for k = 1).
+    glwe_dims: tuple = (1, 2)
+    wide_level: int = 768
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)
@@ -123,15 +129,17 @@ class ExecConfig:
             self.seed = os.urandom(32)
         return self.seed
 
-    def params_choice(self, p, norm2=1):
-        """The parameter set a program with plaintext modulus p and noise statistic norm2 is evaluated with."""
+    def params_choice(self, p, norm2=1, wide=False):
+        """The parameter set a program with plaintext modulus p and noise statistic norm2 is evaluated with (`wide`: its levels are
+        launches of a round or more, see `glwe_dims`)."""
         from .params import REFERENCE_MARGIN, choose_params, params_for
         if self.params is None and self.reduced_noise:
             return params_for(p)
         if self.params is None:
             floor = None if self.allow_margin_floor is None else min(self.min_margin, self.allow_margin_floor)
             try:
-                return choose_params(p, norm2, min_margin=self.min_margin, security=self.security, floor_margin=floor)
+                return choose_params(p, norm2, min_margin=self.min_margin, security=self.security, floor_margin=floor,
+                                     glwe_dims=tuple(self.glwe_dims) if wide else (1,))
             except ValueError as e:
                 if floor is not None:
                     raise
@@ -150,18 +158,24 @@ class ExecConfig:
     def context_for(self, p, norm2=1):
         return self.context_of(self.params_choice(p, norm2))
 
-    def choose(self, env, p):
+    def choose(self, env, p, samples=None):
         """(context, fuse) for a program: the parameter set of `params_choice` at the program's norm, and whether the
-        tables of shared sources share their blind rotation (`fuse_tables`).  Leaves in `last_choice` the margin the
+        tables of shared sources share their blind rotation (`fuse_tables`).  `samples`: how many samples it is about to be
+        evaluated on (decides whether its levels are wide enough for the k = 2 sets).  Leaves in `last_choice` the margin the
         program got and the failure probability that goes with it."""
         from .params import bootstrap_cost
         stats = env.stats()
+        wide = False
+        if samples and 2 in self.glwe_dims and stats["nb_bootstrap"]:
+            from .distributed import plan_levels
+            depth = max(1, plan_levels(env.lower())["depth"])
+            wide = stats["nb_bootstrap"] * int(samples) >= self.wide_level * depth
         fstats = env.fusion_stats(p) if self.fuse_tables is not False else None
         if fstats is None or fstats["nb_rotation"] == stats["nb_bootstrap"] or (self.fuse_tables is None and self.params is not None):
-            return self._chosen(self.params_choice(p, stats["norm2_linprod"]), False, stats["norm2_linprod"], stats["nb_bootstrap"])
+            return self._chosen(self.params_choice(p, stats["norm2_linprod"], wide), False, stats["norm2_linprod"], stats["nb_bootstrap"])
         fused = self.params_choice(p, fstats["norm2_linprod"])
         if self.fuse_tables is not True:
-            plain = self.params_choice(p, stats["norm2_linprod"])
+            plain = self.params_choice(p, stats["norm2_linprod"], wide)
             if not bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]:
                 return self._chosen(plain, False, stats["norm2_linprod"], stats["nb_bootstrap"])
         return self._chosen(fused, True, fstats["norm2_linprod"], stats["nb_bootstrap"])
@@ -483,11 +497,11 @@ class LutExecEnv:
         p = cfg.fbs_size or min_fbs_size(low["tables"])
         for t in low["tables"]:
             assert table_is_valid(t, p), "table %s cannot be evaluated by one bootstrap at fbs_size %d" % (t, p)
-        ctx, fuse = cfg.choose(self, p)
-
         names = low["input_names"]
         cols = [np.asarray(input_values[n]).reshape(-1) for n in names]
         T = max((len(c) for c in cols), default=1)
+        ctx, fuse = cfg.choose(self, p, samples=T)
+
         bits = np.stack([np.broadcast_to(c, (T,)) for c in cols]).astype(np.int64) if cols else np.zeros((0, T), np.int64)
         assert bits.size == 0 or (bits.min() >= 0 and bits.max() <= 1), "inputs are bits"
 

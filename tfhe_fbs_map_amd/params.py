@@ -128,7 +128,7 @@ def bootstrap_cost(prm: Params) -> float:
     sets by the optimizer's `boot_cost` (experiments/analyse_results.py:10); this is the same ranking for this executor."""
     N, n, k, l, t = prm.N, prm.n, prm.k, prm.l_bsk, prm.t_ksk
 
-    def blind(n_, l_, N_, log_n):
+    def blind(n_, l_, N_, log_n, k=k):
         per_coefficient = (k + 1) * ((l_ + 1) * 4.0 * log_n + 7.0 * (k + 1) * l_ + 2.0 * l_ + 12.0)
         return n_ * N_ * per_coefficient * (1.22 if log_n >= 12 else 1.19 if log_n == 11 else 1.0)
 
@@ -139,7 +139,11 @@ def bootstrap_cost(prm: Params) -> float:
     # whole-CU kernel, which has the registers for it: 17.1 ms per 1024 bootstraps at n = 758 against 21.9 ms at n = 766 with one
     # bit per step (round 3: what the 128-bit sets for p = 31 now take)
     pairs = 1.0 if prm.bsk_group != 2 else (0.74 if l == 1 else 0.79 if (l == 2 and prm.log_n_poly == 11) else 1.25)
-    return 0.988 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10) + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
+    # GLWE dimension k = 2 at N = 1024 (k_blind_rotate_pairs_k2, round 3: three wave-private 1024-point transforms each way on three
+    # waves per bootstrap, twelve waves per CU), MEASURED: 7.50 ms per 1024 bootstraps at n = 760 against P1024's 9.26
+    if k == 2:
+        pairs = 0.867
+    return 0.988 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10, 1) + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
 # ---- selector ------------------------------------------------------------------------------------------------------
@@ -156,7 +160,7 @@ def _switch_fits(t, g, N):
 
 def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security: int | None = 128,
                   sigma: int | None = None, poly_sizes=(9, 10, 11, 12), n_range=(450, 1200, 4),
-                  floor_margin: float | None = None, groups=(1, 2)) -> Params:
+                  floor_margin: float | None = None, groups=(1, 2), glwe_dims=(1,)) -> Params:
     """Cheapest parameter set (n, N, l, beta, t, gamma and both noises) for plaintext modulus p and squared 2-norm
     `norm2` whose modelled margin is at least `min_margin` standard deviations -- what the reference obtains from its
     patched optimizer for (precision, sq_norm2) (experiments/add_exec_estimates.py:9-16, concrete.patch:21-27,163).
@@ -166,6 +170,11 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     switch over 1..23 levels of 1..6 bits.  security = None with `sigma`: the same search at a fixed noise (the
     reduced-noise benchmark setting).  `groups`: key bits per blind-rotation step to consider (2 = the multi-bit form: half
     the steps on bundles of three GGSW samples, 1.5x the key, more noise per step; built for N >= 1024, l <= 5, even n).
+    `glwe_dims`: GLWE dimensions to consider.  k = 2 is built at N = 1024 with two key bits per step and one gadget level
+    (k_blind_rotate_pairs_k2): the noise floor of k N = 2048 on 1024-point transforms, 0.81 of k = 1 at N = 2048 per bootstrap in
+    launches of a round (1 024) or more -- but a launch of any size takes a whole round's 7 ms where the k = 1 sets have their
+    one-bootstrap-per-CU kernels (2.8 ms up to 256), so it is for WIDE levels: callers that know their launch sizes ask for it
+    (ExecConfig does, by the program's bootstraps per level times the samples).
     Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
     (p too large for N <= 4096 at this security level); with `floor_margin` the requirement is first relaxed in steps of
     half a sigma down to that floor."""
@@ -174,13 +183,12 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
         m = min_margin
         while True:
             try:
-                return choose_params(p, norm2, m, security, sigma, poly_sizes, n_range, None, groups)
+                return choose_params(p, norm2, m, security, sigma, poly_sizes, n_range, None, groups, glwe_dims)
             except ValueError:
                 if m <= floor_margin:
                     raise
                 m = max(floor_margin, m - 0.5)
     q = float(MODULUS)
-    k = 1
     ns = np.arange(*n_range, dtype=np.float64)
     if security is not None:
         s_lwe = np.array([sigma_min(int(n), security) for n in ns]) / q
@@ -188,7 +196,9 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
         s_lwe = np.full(ns.shape, float(sigma if sigma is not None else REDUCED_SIGMA) / q)
     need = (1.0 / (4.0 * p) / min_margin) ** 2              # largest admissible variance
     best = None
-    for log_n in poly_sizes:
+    for k, log_n in [(k_, ln) for k_ in glwe_dims for ln in poly_sizes]:
+        if k == 2 and (log_n != 10 or 2 not in groups):
+            continue                                        # what the k = 2 kernel is built for
         N = 1 << log_n
         s_glwe = (sigma_min(k * N, security) if security is not None else (sigma if sigma is not None else REDUCED_SIGMA)) / q
         v_ms = (1 + ns / 4.0) / (12.0 * (2.0 * N) ** 2)
@@ -196,6 +206,8 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
             continue
         for (l, beta), group in [((l_, b_), g_) for (l_, b_) in _GADGETS for g_ in groups]:
             if group == 2 and (log_n < 10 or l > 5):
+                continue
+            if k == 2 and (group != 2 or l != 1):
                 continue
             B = 2.0 ** beta
             key_term = (k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2
@@ -205,7 +217,7 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
             if (room <= 0).all():
                 continue
             for t, g in _SWITCHES:
-                if not _switch_fits(t, g, N):
+                if not _switch_fits(t, g, k * N):
                     continue
                 b2 = 2.0 ** g
                 v_ks = k * N * (t * (b2 * b2 + 2) / 12.0 * s_lwe ** 2 + 0.5 / (12.0 * b2 ** (2 * t)))
