@@ -380,12 +380,13 @@ def run_batch(args, rank, world, local, dist):
         sec = result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
         result["shared_rotations"] = shared_rotations_leg(local)
         # (the headline shape is BASELINE's benchmark set at reduced noise; what a deployment runs, in one line of `config`)
-        p4 = sec["n1024_p4"]
+        p4 = sec["n1024_p4"].get("k2", sec["n1024_p4"])
         result["config"]["secure_summary"] = (
-            "128-bit parameter sets, same batch: p=15 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step); p=4 at N=1024 %.0f FBS/s (n=%d l=%d); "
-            "p=31 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step)"
-            % (sec["value"], sec["params"]["n"], sec["params"]["N"], sec["params"]["l"], sec["params"]["key_bits_per_step"],
-               p4["value"], p4["params"]["n"], p4["params"]["l"], sec["p31"]["value"], sec["p31"]["params"]["n"],
+            "128-bit parameter sets, same batch: p=15 %.0f FBS/s (n=%d N=%d k=%d l=%d, %d key bits per step%s); p=4 at N=1024 %.0f FBS/s "
+            "(n=%d k=%d l=%d); p=31 %.0f FBS/s (n=%d N=%d l=%d, %d key bits per step)"
+            % (sec["value"], sec["params"]["n"], sec["params"]["N"], sec["params"]["k"], sec["params"]["l"], sec["params"]["key_bits_per_step"],
+               "; k=1 N=%d: %.0f" % (sec["k1"]["params"]["N"], sec["k1"]["value"]) if "k1" in sec else "",
+               p4["value"], p4["params"]["n"], p4["params"]["k"], p4["params"]["l"], sec["p31"]["value"], sec["p31"]["params"]["n"],
                sec["p31"]["params"]["N"], sec["p31"]["params"]["l"], sec["p31"]["params"]["key_bits_per_step"]))
     return result
 
@@ -470,13 +471,20 @@ def secure_leg(B, local, steps):
         ctx.close()
         return rec
 
-    rec = one(choose_params(15, 70))
+    # a batch of a round or more is what the k = 2 sets are for (GLWE dimension 2 at N = 1024: `glwe_dims`, as ExecConfig asks for
+    # programs with wide levels); smaller batches and the sets beside it are k = 1
+    wide = B >= 768
+    rec = one(choose_params(15, 70, glwe_dims=(1, 2) if wide else (1,)))
+    if rec["params"]["k"] != 1:
+        rec["k1"] = dict(one(choose_params(15, 70)), note="the k = 1 choice for the same (p, norm2): N = 2048, what launches below a round run on")
     if rec["params"]["key_bits_per_step"] != 1:
         rec["one_key_bit_per_step"] = one(choose_params(15, 70, groups=(1,)))
     # the metric names N = 1024: at 128-bit noise that polynomial size carries small plaintext moduli only -- p = 4 is the
     # reference's own Trivium / Kreyvium comparison point (experiments/analyse_results.py:317)
     small = choose_params(4, 2)
     rec["n1024_p4"] = dict(one(small), note="128-bit set for p = 4 at norm2 = 2: the N = 1024 kernels at a secure parameter set")
+    if wide and choose_params(4, 2, glwe_dims=(1, 2)).k == 2:
+        rec["n1024_p4"]["k2"] = one(choose_params(4, 2, glwe_dims=(1, 2)))
     # BASELINE configs[4] (fbs_size = 31; no non-power-of-two N here: the 128-bit set is N = 2048 with two gadget levels)
     big = choose_params(31, 325)
     rec["p31"] = dict(one(big), note="128-bit set for p = 31 at norm2 = 325 (BASELINE configs[4]: fbs_size = 31)")

@@ -5,6 +5,7 @@
 #   sets: p1024 (bench.py headline), cu256 (bench.py --batch 256: one bootstrap per CU), secure (128-bit p = 15, two key bits per
 #         step), secure1 (one key bit per step), p31 (config 5: 128-bit set for p = 31, two key bits per step on whole CUs),
 #         p31g1 (the same with one key bit per step), p63 (N = 4096, one key bit per step), p4 (N = 1024 128-bit set),
+#         securek2 / p4k2 (GLWE dimension k = 2 at N = 1024: k_blind_rotate_pairs_k2 at the 128-bit sets for p = 15 and p = 4),
 #         secure256 / p31cu (the p = 15 and p = 31 sets at one bootstrap per CU), lean512 (bench.py --batch 512: two workgroups per CU)
 TAG=${1:-r03}; shift
 SETS=${@:-p1024 cu256 secure p31}
@@ -36,6 +37,8 @@ for S in $SETS; do
     p31g1)   run_set p31g1 python3 tools/secure_bench.py 1024 4 31 325 1 ;;
     p63)     run_set p63 python3 tools/secure_bench.py 1024 3 63 100 ;;
     p4)      run_set p4 python3 tools/secure_bench.py 1024 5 4 2 ;;
+    securek2) run_set securek2 python3 tools/secure_bench.py 1024 5 15 70 k2 ;;
+    p4k2)    run_set p4k2 python3 tools/secure_bench.py 1024 5 4 2 k2 ;;
     secure256) run_set secure256 python3 tools/secure_bench.py 256 8 15 70 ;;
     p31cu)   run_set p31cu python3 tools/secure_bench.py 256 6 31 325 ;;
     lean512) run_set lean512 python3 bench.py --batch 512 --steps 10 --cpu-sample 0 --no-secure ;;
