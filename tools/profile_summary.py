@@ -11,7 +11,7 @@ root = sys.argv[1]
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_]+)\s*(<[^>]*>)?", name)
+    m = re.search(r"(k_[a-z_0-9]+)\s*(<[^>]*>)?", name)
     if not m:
         return name
     k = (m.group(1) + (m.group(2) or "")).replace(" ", "")
