@@ -58,7 +58,8 @@ def measure(name, T, ranks_list, all_ranks, secure):
     p = int(name.rsplit("_p", 1)[-1])
     if secure:
         from tfhe_fbs_map_amd import choose_params
-        prm = choose_params(p, env.stats()["norm2_linprod"])
+        # (--secure k2: GLWE dimension 2 admitted -- for programs whose per-RANK slices of a level are still a round or more)
+        prm = choose_params(p, env.stats()["norm2_linprod"], glwe_dims=(1, 2) if secure == "k2" else (1,))
     else:
         prm = params_for(p)
     ctx = Context(prm, seed=1)
@@ -161,7 +162,8 @@ def main():
     ap.add_argument("--samples", default="1000,64")
     ap.add_argument("--ranks", default="2,4,8")
     ap.add_argument("--all-ranks", action="store_true")
-    ap.add_argument("--secure", action="store_true", help="the 128-bit set chosen for each program instead of the reduced-noise benchmark set")
+    ap.add_argument("--secure", nargs="?", const="k1", default=None, choices=["k1", "k2"],
+                    help="the 128-bit set chosen for each program instead of the reduced-noise benchmark set (k2: GLWE dimension 2 admitted)")
     ap.add_argument("--skip", default="trivium_stream_v2__search_p15:1000", help="circuit:samples pairs to leave out (minutes of GPU each)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scale_emulation.json"))
     args = ap.parse_args()
