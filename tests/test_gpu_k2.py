@@ -100,3 +100,42 @@ def test_eval_takes_k2_for_wide_levels_only():
     ins, _ = subsample(rec, 200)
     env.eval(ins, config=cfg)
     assert cfg.last_choice["params"].k == 1
+
+
+def test_noise_model_holds_at_k2(nat):
+    """The variance model the selector rests on, at the k = 2 set for (15, 70): the measured bootstrap OUTPUT noise (the blind
+    rotation's term: k + 1 = 3 key polynomials' noise per step, rounding seen through a key of k N = 2048 bits) against
+    params.variances, and every output far inside its box.  The modulus switch onto 2N = 2048 slots - four times the variance of
+    the N = 2048 sets', the term that sets n - is checked by chaining: bootstraps of bootstrap outputs scaled to norm2 70 decrypt."""
+    from tfhe_fbs_map_amd.params import choose_params, variances
+    prm = choose_params(15, 70, glwe_dims=(1, 2))
+    assert prm.k == 2
+    ctx, o = nat.Context(prm, seed=13), orc.Oracle(prm, seed=13)
+    rng = np.random.default_rng(5)
+    table = [0] + [int(v) for v in rng.integers(0, 2, 14)]
+    B = 400
+    msgs = rng.integers(0, 15, B)
+    cts = ctx.encrypt(msgs, nonce0=900)
+    tv = ctx.tvset([table])
+    out = ctx.bootstrap_batch(tv, cts)
+    assert np.array_equal(ctx.decrypt(out), [table[m] for m in msgs])
+    phase = o.phase(out).astype(object)
+    want = np.array([table[m] for m in msgs], dtype=object) * (2 * o.delta_half)
+    err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
+    predicted = np.sqrt(variances(prm)[0]) * orc.Q
+    measured = float(np.sqrt(np.mean(err ** 2)))
+    assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)
+    assert err.max() < 0.1 * orc.Q / (4 * 15)
+    # a linear combination of squared norm 70 of bootstrap outputs (8 x b0 + 2 x b1 + b2 + b3: 64 + 4 + 1 + 1), bootstrapped again
+    bits = np.array([table[m] for m in msgs])
+    idx = rng.integers(0, B, (4, B))
+    coefs = np.array([8, 2, 1, 1])
+    value = (coefs[:, None] * bits[idx]).sum(0)                      # 0 .. 12 < 15
+    lc = np.zeros_like(out)
+    for c, row in zip(coefs, idx):
+        lc = (lc + int(c) * out[row].astype(object)) % orc.Q
+    lc = lc.astype(np.uint64)
+    ident = list(range(15))
+    again = ctx.bootstrap_batch(ctx.tvset([ident]), lc)
+    assert np.array_equal(ctx.decrypt(again), value)
+    ctx.close()
