@@ -55,8 +55,10 @@ def recipe(name):
         return dict(log_n=11, l=1, beta=20, group=2, count=CUS - 9, knobs={})
     if name == "k_blind_rotate_cu_pairs<11,2>":           # ... with two gadget levels: every launch, round after round
         return dict(log_n=11, l=2, beta=10, group=2, count=CUS + 21, knobs={})
-    if name == "k_blind_rotate_pairs_k2<10>":             # GLWE dimension k = 2: four bootstraps per workgroup, a ragged last one
-        return dict(log_n=10, l=1, beta=20, group=2, k=2, count=CUS + 41, knobs={})
+    m = re.fullmatch(r"k_blind_rotate_pairs_k2<10,(\d)>", name)
+    if m:                                                 # GLWE dimension k = 2: one, two or four bootstraps per workgroup, a ragged last one
+        fpw = int(m.group(1))
+        return dict(log_n=10, l=1, beta=20, group=2, k=2, count={1: 41, 2: CUS + 41, 4: 2 * CUS + 41}[fpw], knobs={})
     m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))

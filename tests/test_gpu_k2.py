@@ -34,7 +34,7 @@ def test_ragged_batches_bit_exact(nat, beta):
     prm = toy(beta_bsk=beta)
     ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
     tv = ctx.tvset(TABLES)
-    for B in (1, 2, 3, 4, 5, 7, 21, 64, 301):
+    for B in (1, 2, 3, 4, 5, 7, 21, 64, 301, 600):
         msgs = np.arange(B) % 7
         ids = (np.arange(B) % 4).astype(np.uint32)
         msgs[ids == 1] = np.arange(B)[ids == 1] % 14
@@ -46,7 +46,8 @@ def test_ragged_batches_bit_exact(nat, beta):
         ctx.profile(True)
         ctx.profile_read(reset=True)
         got = ctx.bootstrap_batch(tv, cts, ids)
-        assert "k_blind_rotate_pairs_k2<10>" in ctx.profile_kernels()
+        want = "k_blind_rotate_pairs_k2<10,%d>" % (1 if B <= 256 else 2)
+        assert want in ctx.profile_kernels(), (want, ctx.profile_kernels())
         ref, _ = o.bootstrap_batch(cts, TABLES, ids)
         assert np.array_equal(got, ref), B
     ctx.close()

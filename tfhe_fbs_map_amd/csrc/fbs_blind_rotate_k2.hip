@@ -23,11 +23,15 @@
 
 namespace fbs {
 
-template <int LOGN>
-__global__ __launch_bounds__(768) void k_blind_rotate_pairs_k2(BrArgs a) {
+// FPW: bootstraps per workgroup.  4 = the throughput shape above (twelve waves, three per SIMD); 1 and 2 = launches that leave
+// most of the chip empty (at most one / two bootstraps per CU): the same code with one or two bootstraps' three waves on a CU's
+// four SIMDs, every wave (nearly) alone on its SIMD -- a step's latency is then one wave's instruction chain instead of three
+// waves' sharing an issue port.
+template <int LOGN, int FPW>
+__global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
     using W = SplitNtt<LOGN, 6>;
     static_assert(W::HAS_EVAL_POSITION && W::E == 16, "one wave per polynomial, 16 coefficients per lane");
-    constexpr int N = W::N, E = W::E, LANES = W::LANES, K1 = 3, FPW = 4;
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, K1 = 3;
     constexpr int GLOG = W::EVAL_GROUP_LOG2, G = 1 << GLOG;
     // [wave][N] exchange buffers (wave = 3 * bootstrap + component), forward and inverse per-lane twiddle tables, psi^x (x < N,
     // transposed as in k_blind_rotate_pairs: word (x mod G) N/G + x / G)
@@ -40,14 +44,14 @@ __global__ __launch_bounds__(768) void k_blind_rotate_pairs_k2(BrArgs a) {
     typename W::Xchg xc{mine, 0};
     xc.stride = 0;
     Twiddles twf(tables, a.tw_fwd), twi(tables + N, a.tw_inv);
-    for (uint32_t x = threadIdx.x; x < (uint32_t)N; x += 768u) {
+    for (uint32_t x = threadIdx.x; x < (uint32_t)N; x += 192u * FPW) {
         tables[x] = a.tw_fwd[W::LANE_TABLE_OFFSET + x];
         tables[N + x] = a.tw_inv[W::LANE_TABLE_OFFSET + x];
         tables[2 * N + (x & (G - 1)) * (N / G) + (x >> GLOG)] = a.psi_pow[x];
     }
     __syncthreads();
 
-    // a workgroup past the end of a batch that is not a multiple of four repeats the last bootstrap (its waves must keep meeting
+    // a workgroup past the end of a batch that is not a multiple of FPW repeats the last bootstrap (its waves must keep meeting
     // the others at the barriers) and writes nothing
     const size_t f_want = (size_t)blockIdx.x * FPW + sub;
     const bool live = f_want < a.count;
@@ -194,11 +198,23 @@ __global__ __launch_bounds__(768) void k_blind_rotate_pairs_k2(BrArgs a) {
 bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
     if (p.k != 2 || p.log_n_poly != 10 || ctx->group != 2 || p.l_bsk != 1) return false;
-    *kernel = "k_blind_rotate_pairs_k2<10>";
-    hipLaunchKernelGGL((k_blind_rotate_pairs_k2<10>), dim3((unsigned)((a.count + 3) / 4)), dim3(768), 0, stream, a);
+    // up to one bootstrap per CU: one per workgroup; up to two: two; beyond: four (measured per launch: tools/k2_check.py)
+    const size_t cus = (size_t)ctx->cu_count;
+    if (a.count <= cus && ctx->tune.br_cu_max_per_cu >= 1) {
+        *kernel = "k_blind_rotate_pairs_k2<10,1>";
+        hipLaunchKernelGGL((k_blind_rotate_pairs_k2<10, 1>), dim3((unsigned)a.count), dim3(192), 0, stream, a);
+    } else if (a.count <= 2 * cus && ctx->tune.br_cu_max_per_cu >= 1) {
+        *kernel = "k_blind_rotate_pairs_k2<10,2>";
+        hipLaunchKernelGGL((k_blind_rotate_pairs_k2<10, 2>), dim3((unsigned)((a.count + 1) / 2)), dim3(384), 0, stream, a);
+    } else {
+        *kernel = "k_blind_rotate_pairs_k2<10,4>";
+        hipLaunchKernelGGL((k_blind_rotate_pairs_k2<10, 4>), dim3((unsigned)((a.count + 3) / 4)), dim3(768), 0, stream, a);
+    }
     return true;
 }
 
-void blind_rotate_k2_catalog(std::vector<std::string> *out) { out->push_back("k_blind_rotate_pairs_k2<10>"); }
+void blind_rotate_k2_catalog(std::vector<std::string> *out) {
+    for (const char *name : {"k_blind_rotate_pairs_k2<10,1>", "k_blind_rotate_pairs_k2<10,2>", "k_blind_rotate_pairs_k2<10,4>"}) out->push_back(name);
+}
 
 }  // namespace fbs

@@ -13,7 +13,7 @@ toy = Params(n=16, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=8, gamma_ksk=
 ctx, o = Context(toy, seed=4), orc.Oracle(toy, seed=4)
 tabs = [[0, 1, 1, 0, 1, 0, 0], [0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1], [0, 1, 2, 3, 2, 1, 0], [1, 1, 1, 0, 1, 0, 0, 1, 1, 1]]
 tv = ctx.tvset(tabs)
-for B in (1, 2, 3, 4, 5, 7, 21, 64, 301):
+for B in (1, 2, 3, 4, 5, 7, 21, 64, 301, 515, 1029):
     msgs = np.arange(B) % 7
     ids = (np.arange(B) % 4).astype(np.uint32)
     msgs[ids == 1] = np.arange(B)[ids == 1] % 14
@@ -36,7 +36,7 @@ ctx = Context(prm, seed=1)
 rng = np.random.default_rng(42)
 tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
 tv = ctx.tvset(tables)
-for Bq in (B, 256, 512, 2048):
+for Bq in (B, 64, 256, 384, 512, 768, 2048):
     msgs = rng.integers(0, 15, Bq)
     ids = (np.arange(Bq) % 16).astype(np.uint32)
     d_in = torch.from_numpy(ctx.encrypt(msgs, nonce0=0).view(np.int64)).cuda()
