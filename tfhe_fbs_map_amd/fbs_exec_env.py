@@ -114,11 +114,12 @@ class ExecConfig:
     # left is compared with the unfused choice.  With explicit `params` None means off (their margin is the caller's).
     fuse_tables: bool | None = None
     # GLWE dimensions the selector may use.  k = 2 (N = 1024, two key bits per step: k_blind_rotate_pairs_k2) is 0.81 of the k = 1
-    # sets' cost per bootstrap in launches of a round (1 024 bootstraps) or more, but takes a whole round's 7 ms for a launch of any
-    # size where the k = 1 sets have their one-bootstrap-per-CU kernels: `choose` admits it for programs whose levels average
-    # `wide_level` bootstraps (gates of the level x samples) or more, and only without shared rotations (built for k = 1).
+    # sets' cost per bootstrap in launches of a round (1 024 bootstraps) or more and ahead from ~400 per launch (512: 5.06 against
+    # 5.35 ms); up to one bootstrap per CU the k = 1 sets' whole-CU kernels are faster (2.8 against 3.6 ms per launch).  `choose`
+    # admits it for programs whose levels average `wide_level` bootstraps (gates of the level x samples) or more, and only without
+    # shared rotations (built for k = 1).
     glwe_dims: tuple = (1, 2)
-    wide_level: int = 768
+    wide_level: int = 400
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)

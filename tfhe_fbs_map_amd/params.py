@@ -172,8 +172,8 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     the steps on bundles of three GGSW samples, 1.5x the key, more noise per step; built for N >= 1024, l <= 5, even n).
     `glwe_dims`: GLWE dimensions to consider.  k = 2 is built at N = 1024 with two key bits per step and one gadget level
     (k_blind_rotate_pairs_k2): the noise floor of k N = 2048 on 1024-point transforms, 0.81 of k = 1 at N = 2048 per bootstrap in
-    launches of a round (1 024) or more -- but a launch of any size takes a whole round's 7 ms where the k = 1 sets have their
-    one-bootstrap-per-CU kernels (2.8 ms up to 256), so it is for WIDE levels: callers that know their launch sizes ask for it
+    launches of a round (1 024) or more and ahead from ~400 per launch -- but up to one bootstrap per CU it takes 3.4-3.6 ms
+    where the k = 1 sets' whole-CU kernels take 2.8, so it is for WIDE levels: callers that know their launch sizes ask for it
     (ExecConfig does, by the program's bootstraps per level times the samples).
     Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
     (p too large for N <= 4096 at this security level); with `floor_margin` the requirement is first relaxed in steps of
