@@ -46,7 +46,7 @@ def test_ragged_batches_bit_exact(nat, beta):
         ctx.profile(True)
         ctx.profile_read(reset=True)
         got = ctx.bootstrap_batch(tv, cts, ids)
-        want = "k_blind_rotate_pairs_k2<10,%d>" % (1 if B <= 256 else 2)
+        want = "k_blind_rotate_pairs_k2<10,%d>" % (1 if B <= 256 else 2 if B <= 512 else 4)
         assert want in ctx.profile_kernels(), (want, ctx.profile_kernels())
         ref, _ = o.bootstrap_batch(cts, TABLES, ids)
         assert np.array_equal(got, ref), B
