@@ -54,6 +54,11 @@ BUTTERFLY_INSTR = 8        # exact 46-bit modular butterfly on the FP64 pipe: 6-
 MAC_INSTR = 7              # exact product + lazy accumulate
 
 
+def pmc_key(kernel, n, units):
+    """Key of a kernel's PMC record: the instantiation, the LWE dimension of the parameter set and the bootstraps per launch."""
+    return "%s@n=%d@units=%d" % (kernel, n, units)
+
+
 def kernel_sources_sha256():
     """What the offline PMC record must have been collected on: the kernel sources as they are now."""
     import hashlib
@@ -82,6 +87,8 @@ def parse_args(argv=None):
     ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
     ap.add_argument("--no-secure", action="store_true", help="skip the secure-parameter-set leg")
+    ap.add_argument("--oracle-sample", type=int, default=32,
+                    help="ciphertexts of every secure leg's timed batch checked word for word against the scalar oracle (0: skip)")
     ap.add_argument("--secure", action="store_true",
                     help="circuit: the 128-bit parameter set choose_params returns for the program's (p, norm2) instead of the "
                          "reduced-noise benchmark set")
@@ -263,7 +270,7 @@ def algorithmic_instr_per_bootstrap(prm):
     return steps * (butterflies * BUTTERFLY_INSTR + macs * MAC_INSTR) / 64.0
 
 
-def roofline_record(prm, prof, kernels, B, steps):
+def roofline_record(prm, prof, kernels, B, steps, cus=256):
     """The dominant kernel is the blind rotation.  It is bound by FP64 VALU issue, not by HBM: every workgroup walks the
     bootstrapping key in step, so after the first touch the key comes out of L2 / Infinity Cache (PMC: a few % of the
     algorithmic bytes reach the fabric).
@@ -288,7 +295,7 @@ def roofline_record(prm, prof, kernels, B, steps):
     N, n, k = prm.N, prm.n, prm.k
     # a launch the launcher cuts (whole rounds as four-bootstrap workgroups + the leftovers in another shape) shows as two
     # kernels: each is reported with its own time, and the dominant one is priced on the bootstraps IT ran
-    per_round = 4 * 256
+    per_round = 4 * cus                    # a round of the whole-CU shape: four bootstraps per CU (cus = fbs_ctx_stat cu_count)
     if len(br_all) == 1:
         units = B
     elif name == "k_blind_rotate<10,6,3,4>":
@@ -320,7 +327,8 @@ def roofline_record(prm, prof, kernels, B, steps):
     pmc = None
     if os.path.exists(PMC_FILE):
         records = json.load(open(PMC_FILE))
-        pmc = records.get("%s@%d" % (name, units)) or records.get(name)
+        # (records of round 3 were keyed by the kernel name, "@units" at most: one kernel at two parameter sets could not both be held)
+        pmc = records.get(pmc_key(name, n, units)) or records.get("%s@%d" % (name, units)) or records.get(name)
     if pmc is None:
         rec["pmc"] = "no record for %s in %s" % (name, os.path.relpath(PMC_FILE, ROOT))
     elif pmc.get("csrc_sha256") != kernel_sources_sha256():
@@ -372,12 +380,19 @@ def run_batch(args, rank, world, local, dist):
                                        "(a kernel benchmark shape, not a secure configuration: see `params` and `secure`)" % B,
                               batch_per_gpu=B, parallelism="replicas of the batch per GPU, keys replicated, no collective",
                               device=ctx.device_info, params=params_record(prm)),
-                  decrypt_ok=ok, roofline=roofline_record(prm, prof, prof["kernels"], B, args.steps))
+                  decrypt_ok=ok, roofline=roofline_record(prm, prof, prof["kernels"], B, args.steps, ctx.stat("cu_count")))
     if world == 1 and args.cpu_sample != 0:
         result["cpu_baseline"] = cpu_baseline(prm, tables, cts, ids, out, args.cpu_sample)
     ctx.close()
     if world == 1 and not args.no_secure:
-        sec = result["secure"] = secure_leg(B, local, max(3, args.steps // 2))
+        sec = result["secure"] = secure_leg(B, local, max(3, args.steps // 2), args.oracle_sample)
+        # the deployable number beside the benchmark shape: the same batch at the 128-bit set for p = 15, norm2 70 (N = 1024 when
+        # the batch is wide enough for the k = 2 set).  `value` stays on BASELINE's P1024 configuration.
+        result["value_secure"] = dict(value=sec["value"], unit="FBS/s", decrypt_ok=sec["decrypt_ok"], bit_exact_vs_oracle=sec["bit_exact_vs_oracle"],
+                                      what="the same batch at the 128-bit parameter set choose_params(15, 70) returns for a batch of this width",
+                                      params={k: sec["params"][k] for k in ("n", "N", "k", "l", "beta", "t", "gamma", "p", "key_bits_per_step",
+                                                                            "security_bits_estimate")},
+                                      margin_sigmas_at_norm2_70=sec["margin_sigmas_at_norm2_70"], kernel=sec["blind_rotate_kernel"])
         result["shared_rotations"] = shared_rotations_leg(local)
         # (the headline shape is BASELINE's benchmark set at reduced noise; what a deployment runs, in one line of `config`)
         p4 = sec["n1024_p4"].get("k2", sec["n1024_p4"])
@@ -450,7 +465,24 @@ def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p1
                                      predicted_speedup_over_one_gpu=round(pick["predicted_speedup"], 2)), legs=legs)
 
 
-def secure_leg(B, local, steps):
+def oracle_sample_check(prm, tables, cts, ids, gpu_out, sample):
+    """A bounded sample of a leg's timed batch -- both ends of the launch (every sub-slot of the first and of the last workgroup)
+    and a spread in between -- bootstrapped by the scalar oracle on the same keys and compared word for word with what the GPU
+    left.  The oracle is the checker here, after the timed region; it is never what is measured."""
+    import numpy as np
+    if sample <= 0:
+        return dict(bit_exact_vs_oracle=None, oracle_sample="skipped (--oracle-sample 0)")
+    from oracle import tfhe_oracle
+    B = len(cts)
+    edge = max(1, min(8, sample // 4))
+    spread = np.random.default_rng(B).integers(0, B, max(0, sample - 2 * edge))
+    pick = np.unique(np.concatenate([np.arange(min(edge, B)), np.arange(max(0, B - edge), B), spread]))
+    ref, _ = tfhe_oracle.Oracle(prm, seed=1).bootstrap_batch(cts[pick], tables, ids[pick])
+    return dict(bit_exact_vs_oracle=bool(np.array_equal(ref, gpu_out[pick])),
+                oracle_sample="%d ciphertexts of the timed batch (both ends and a spread), scalar oracle on the same keys" % len(pick))
+
+
+def secure_leg(B, local, steps, oracle_sample=32):
     """The same batch at the parameter set `choose_params` returns for p = 15 at norm2 = 70 (the 16x16 multiplier's and
     the adder's linear combinations), 128-bit noise, 6 sigma: what a deployment would run.  The selector takes two key bits
     per blind-rotation step there (bsk_group = 2); the one-bit-per-step choice is timed beside it."""
@@ -459,10 +491,11 @@ def secure_leg(B, local, steps):
 
     def one(prm):
         ctx = Context(prm, seed=1, device=local)
-        elapsed, prof, *_, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
+        elapsed, prof, tables, cts, ids, _, out, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
         br, ks = prof["blind_rotate"], prof["keyswitch"]
-        roof = roofline_record(prm, prof, prof["kernels"], B, steps)
-        rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok, params=params_record(prm),
+        roof = roofline_record(prm, prof, prof["kernels"], B, steps, ctx.stat("cu_count"))
+        rec = dict(value=B * steps / elapsed, unit="FBS/s", steps=steps, batch=B, decrypt_ok=ok,
+                   **oracle_sample_check(prm, tables, cts, ids, out, oracle_sample), params=params_record(prm),
                    roofline={k: roof[k] for k in ("kernel", "avg_launch_ms", "frac", "algorithmic_frac", "valu_frac", "issue_cycle_frac",
                                                   "fabric_GBps", "pmc")} if roof else None,
                    margin_sigmas_at_norm2_70=round(margin_sigmas(prm, 70), 2), modelled_cost_vs_p1024=round(bootstrap_cost(prm), 3),

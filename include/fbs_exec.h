@@ -10,7 +10,12 @@
  * behind.
  *
  * Conventions: every function returns 0 on success and a negative FBS_E_* code
- * on failure (never throws, never aborts); `fbs_last_error` gives the text.
+ * on failure (never throws, never aborts: every entry point is an exception
+ * barrier -- a host allocation that fails inside the library comes back as
+ * FBS_E_NOMEM, any other internal exception as FBS_E_INVALID -- and counts are
+ * checked against FBS_MAX_* before anything is sized by them; what the library
+ * cannot check is that a caller's array is as long as its count says);
+ * `fbs_last_error` gives the text.
  * Host buffers are caller-allocated, C-contiguous, 64-bit words unless stated;
  * the library owns device memory and keys behind opaque handles.  A context is
  * bound to one GPU and must be driven by one host thread at a time.  There is
@@ -45,6 +50,7 @@ extern "C" {
 #define FBS_E_STATE (-3)     /* call out of order (e.g. eval before keygen)       */
 #define FBS_E_TABLE (-4)     /* table violates the negacyclic contract for p      */
 #define FBS_E_POLY_SIZE (-5) /* polynomial size rejected (see fbs_poly_size_check) */
+#define FBS_E_NOMEM (-6)     /* the HOST could not allocate what the arguments ask for */
 
 typedef struct fbs_params {
     uint32_t n;          /* small LWE dimension (P1024: 630)                      */
@@ -125,9 +131,18 @@ const char *fbs_device_info(const fbs_ctx *ctx);
  * uploaded, transformed to the NTT domain on the GPU and kept resident, as is
  * the key-switching key. */
 int fbs_keygen(fbs_ctx *ctx);
-/* word counts of { sk_lwe, sk_glwe, bsk, ksk } in the standard (coefficient)
- * layout  bsk[G][(k+1)l][k+1][N],  ksk[kN][t][n+1];  G = n GGSW samples, or with
- * bsk_group = 2 three per pair (s0, s1) of key bits -- of s0(1-s1), (1-s0)s1, s0 s1 -- G = 3n/2 */
+/* word counts of { sk_lwe, sk_glwe, bsk, ksk } in the standard (coefficient) layout:
+ *   sk_lwe[n], sk_glwe[k][N] (bit c N + j = coefficient j of key polynomial S_c; read flat it is the key of the
+ *     extracted LWE ciphertexts, dimension k N);
+ *   bsk[G][(k+1) l][k+1][N]: GGSW sample g, row rr = comp l + lv (comp = 0 .. k: the GLWE component the gadget
+ *     factor sits on, k = the body; lv = gadget level), then the row's k + 1 polynomials: columns 0 .. k-1 the mask
+ *     A_0 .. A_(k-1), column k the body B = sum_c A_c S_c + e -- and the message: bit g_lv added to coefficient 0
+ *     of column comp, g_lv = round(q / 2^(beta (lv+1)));
+ *     bsk_group <= 1: G = n, sample g encrypts key bit sk_lwe[g];
+ *     bsk_group = 2 (the default 128-bit sets): G = 3 n / 2, samples 3 i, 3 i + 1, 3 i + 2 belong to the pair
+ *     (s0, s1) = (sk_lwe[2 i], sk_lwe[2 i + 1]) and encrypt s0 (1 - s1), (1 - s0) s1 and s0 s1, in that order;
+ *   ksk[k N][t][n+1]: row (j, v) = LWE under sk_lwe (n mask words, then the body) of sk_glwe[j] h_v,
+ *     h_v = round(q / 2^(gamma (v+1))), j = c N + coefficient. */
 int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]);
 /* test hook: copy keys out (any pointer may be NULL) so a checker can be keyed identically */
 int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk);
@@ -135,7 +150,10 @@ int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uin
  * fbs_key_sizes, instead of fbs_keygen.  Secret keys are binary, every other word a canonical residue (< q); the
  * evaluation keys must encrypt the secrets under this library's gadget conventions (GGSW row
  * (c, l) = GLWE(0) + s g_l on component c, g_l = round(q / 2^(beta (l+1))); key-switching row (j, v) = LWE(s_j h_v)).
- * The secret keys stay on the host and serve fbs_encrypt / fbs_decrypt only. */
+ * The secret keys stay on the host and serve fbs_encrypt / fbs_decrypt only.  Besides the ranges, the call DECRYPTS a few
+ * GGSW samples (first, middle, last; every row) and key-switching rows with the supplied secrets and refuses
+ * (FBS_E_INVALID) keys whose phases are not what this layout says they encrypt, within 16 standard deviations of the
+ * parameter set's noises: a key in another order fails here, not as garbage after the first bootstrap. */
 int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk, const uint64_t *ksk);
 
 /* ---- encrypt / decrypt (host side, big key) ------------------------------
@@ -192,6 +210,9 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
  *   LinearProd i: terms [arg0[i], arg0[i]+arg1[i]) of (term_coef, term_src), constant const_coef[i].
  *   Bootstrap  i: source wire arg0[i], table id arg1[i] (into the fbs_tvset).
  *   outputs: out_wire[o] >= 0 is a wire id; a constant output c is encoded as -1-c. */
+#define FBS_MAX_WIRES (1u << 28)   /* n_inputs + n_instr, and n_outputs, of one program */
+#define FBS_MAX_TERMS (1u << 30)   /* n_terms of one program */
+#define FBS_MAX_TABLES (1u << 20)  /* tables of one fbs_tvset */
 typedef struct fbs_program_desc {
     uint32_t n_inputs, n_instr, n_terms, n_outputs;
     const uint8_t *kind;
@@ -311,6 +332,10 @@ int fbs_search_lincomb_coefs(fbs_searcher *s, const int32_t *x, const int32_t *y
 
 /* ---- debug hook: negacyclic product of two polynomials on the device NTT ---- */
 int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c);
+/* ---- test hook: raises a C++ exception INSIDE the library (kind 0 std::bad_alloc, 1 std::length_error, 2 std::runtime_error,
+ * 3 a non-standard one; else nothing) to show that none crosses this boundary: returns FBS_E_NOMEM, FBS_E_NOMEM,
+ * FBS_E_INVALID, FBS_E_INVALID, FBS_OK, with the text in fbs_last_error(ctx) (ctx may be NULL: no device is touched). */
+int fbs_debug_raise(fbs_ctx *ctx, int kind);
 
 #ifdef __cplusplus
 }

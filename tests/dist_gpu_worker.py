@@ -18,6 +18,7 @@ from tests.helpers import load_fixture, subsample      # noqa: E402
 def main():
     name, T, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
+    k2 = len(sys.argv) > 4 and sys.argv[4] == "k2"      # GLWE dimension 2 at N = 1024: ciphertexts and rows of 2 N + 1 words
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -28,6 +29,9 @@ def main():
     low = env.lower()
     p = max(7, max(len(t) for t in low["tables"]))
     prm = Params(n=12, log_n_poly=10, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=1 << 8)
+    if k2:
+        from tests.helpers import toy_k2
+        prm = toy_k2(p)
     ctx = Context(prm, seed=21)                       # keys replicated: every rank derives them from the seed
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
                    low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fused)

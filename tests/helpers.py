@@ -38,6 +38,15 @@ def load_fixture(name):
     return _cache[name]
 
 
+def toy_k2(p_msg=7, n=12, beta=21):
+    """A toy set of the k = 2 shape (GLWE dimension 2 at N = 1024, one gadget level, two key bits per step): n small enough for
+    the CPU oracle to bootstrap in milliseconds, real N so that the kernels are the shipped ones (k_blind_rotate_pairs_k2 and
+    the whole-CU k = 2 shape, ct_words = 2049 through k_lincomb and the level calls)."""
+    from tfhe_fbs_map_amd import Params
+    return Params(n=n, log_n_poly=10, k=2, l_bsk=1, beta_bsk=beta, t_ksk=8, gamma_ksk=2, p_msg=p_msg, sigma_lwe=1 << 8, sigma_glwe=4,
+                  bsk_group=2)
+
+
 def subsample(rec, T):
     """First T samples of the harness inputs and of the expected outputs."""
     ins = {k: v[:T] for k, v in rec["inputs"].items()}

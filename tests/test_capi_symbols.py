@@ -104,3 +104,58 @@ def test_c_client_bootstraps_on_the_gpu(tmp_path):
     import subprocess
     rc = subprocess.run([_build_c_client(tmp_path)], capture_output=True, text=True)
     assert rc.returncode == 0 and rc.stdout.startswith("ok on gfx950"), rc.stdout + rc.stderr
+
+
+def test_no_exception_crosses_the_boundary():
+    """include/fbs_exec.h: "never throws, never aborts".  Every extern "C" entry point is a function-try-block; the test hook raises
+    what a failing host allocation (std::vector / std::thread sized by caller input) or a library call would raise INSIDE one,
+    and the call comes back with a code and a text -- in this very process, which goes on."""
+    from tfhe_fbs_map_amd import _native
+    lib = _native.lib
+    want = {0: (-6, "out of host memory"), 1: (-6, "out of host memory"), 2: (-1, "internal error: raised on request"),
+            3: (-1, "unknown internal error"), 9: (0, None)}
+    for kind, (code, text) in want.items():
+        assert lib.fbs_debug_raise(None, kind) == code, kind
+        if text:
+            assert text in lib.fbs_last_error(None).decode(), kind
+    # and every entry point of the sources has the barrier: an `extern "C"` definition without `try` would be a hole
+    for src in ("fbs_capi.cpp", "fbs_mapper_search.hip"):
+        text = open(os.path.join(ROOT, "tfhe_fbs_map_amd", "csrc", src)).read()
+        body = text[text.index('extern "C" {'):]
+        for m in re.finditer(r"^(?:int|void|double|const char \*) ?(fbs_\w+)\(([^{};]*?)\) (try )?\{", body, flags=re.M):
+            if m.group(1) in ("fbs_last_error", "fbs_device_info", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms"):
+                continue                                    # one-line accessors of an existing string / number: nothing can throw
+            assert m.group(3), "%s: %s has no function-try-block" % (src, m.group(1))
+
+
+@pytest.mark.gpu
+def test_absurd_counts_come_back_as_codes():
+    """Counts are checked against FBS_MAX_* before anything is sized by them: a program description or a table set with
+    corrupted counts returns FBS_E_INVALID (the arrays behind them are never touched), and the process survives."""
+    import numpy as np
+    from tfhe_fbs_map_amd import Params, _native as nat
+    lib = nat.lib
+    ctx = nat.Context(Params(n=8, log_n_poly=8, p_msg=7), seed=1)
+    tv = ctx.tvset([[0, 1, 1, 0]])
+    one8, one32, one64 = np.zeros(4, np.uint8), np.zeros(4, np.uint32), np.zeros(4, np.int64)
+
+    def load(n_inputs, n_instr, n_terms, n_outputs, kind=one8):
+        d = nat._ProgramDesc(n_inputs=n_inputs, n_instr=n_instr, n_terms=n_terms, n_outputs=n_outputs,
+                             kind=None if kind is None else kind.ctypes.data, arg0=one32.ctypes.data, arg1=one32.ctypes.data,
+                             const_coef=one64.ctypes.data, term_coef=one64.ctypes.data, term_src=one32.ctypes.data, out_wire=one64.ctypes.data)
+        out = ctypes.c_void_p()
+        return lib.fbs_program_load(ctx._h, ctypes.byref(d), tv._h, ctypes.byref(out)), out
+
+    for args in ((0xFFFFFFFF, 2, 0, 0), (1, 0xFFFFFFF0, 0, 0), (2, 2, 0xF0000000, 0), (2, 2, 0, 0xFFFFFFFF), (1 << 27, (1 << 27) + 1, 0, 0)):
+        rc, out = load(*args)
+        assert rc == -1 and not out.value, args
+        assert "program too large" in lib.fbs_last_error(ctx._h).decode()
+    rc, _ = load(1, 2, 0, 0, kind=None)
+    assert rc == -1 and "null array" in lib.fbs_last_error(ctx._h).decode()
+    out = ctypes.c_void_p()
+    assert lib.fbs_tvset_create(ctx._h, one32.ctypes.data, one32.ctypes.data, 0xFFFFFFFF, ctypes.byref(out)) == -1
+    assert "FBS_MAX_TABLES" in lib.fbs_last_error(ctx._h).decode()
+    # the context is as usable as before
+    msgs = np.arange(4)
+    assert np.array_equal(ctx.decrypt(ctx.bootstrap_batch(tv, ctx.encrypt(msgs, nonce0=1))), [0, 1, 1, 0])
+    ctx.close()

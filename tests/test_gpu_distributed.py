@@ -17,13 +17,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name,T", [("adder8__search_p7", 5), ("adder8__basic_p2", 3), ("edge_outputs", 4),
-                                    ("full_adder__search_p7", 1)])        # T = 1: levels narrower than the world, empty slices
-def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T):
+@pytest.mark.parametrize("name,T,flavour", [("adder8__search_p7", 5, ""), ("adder8__basic_p2", 3, ""), ("edge_outputs", 4, ""),
+                                            ("full_adder__search_p7", 1, ""),   # T = 1: levels narrower than the world, empty slices
+                                            ("adder8__search_p7", 5, "k2"), ("edge_outputs", 4, "k2")])   # GLWE dimension 2
+def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T, flavour):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(T), out],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(T), out] + ([flavour] if flavour else []),
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0

@@ -3,8 +3,8 @@ components' exchange buffers with LDS atomics): word for word against the oracle
 import numpy as np
 import pytest
 
-from oracle import tfhe_oracle as orc
-from tests.helpers import load_fixture, subsample
+from oracle import lut_oracle, tfhe_oracle as orc
+from tests.helpers import load_fixture, oracle_eval_program, subsample, toy_k2
 
 pytestmark = pytest.mark.gpu
 
@@ -74,6 +74,80 @@ def test_odd_steps_and_real_size_bit_exact(nat):
     ids = (np.arange(B) % 16).astype(np.uint32)
     out = ctx.bootstrap_batch(tv, ctx.encrypt(msgs, nonce0=100), ids)
     assert np.array_equal(ctx.decrypt(out), [tables[i][m] for i, m in zip(ids, msgs)])
+    ctx.close()
+
+
+@pytest.mark.parametrize("p, norm2", [(15, 70), (4, 2)])
+def test_shipped_k2_sets_at_full_size_against_the_oracle(nat, p, norm2):
+    """What `LutExecEnv.eval` runs by default for wide programs, as the bench runs it: the selector's own k = 2 set (p = 15 at
+    norm2 70: n = 734; p = 4: n = 630) at full n, 1 024 ciphertexts through fbs_bootstrap_batch_dev on the throughput shape
+    k_blind_rotate_pairs_k2<10,4> -- word for word against the oracle on ciphertexts that sit in every sub-slot (bootstrap
+    0 .. 3 of a workgroup = three waves on other SIMDs each) of the first, a middle and the last workgroup, trivial
+    ciphertexts (every step skipped: the bootstrap only keeps its workgroup's barriers company) beside ordinary ones.  Then a
+    launch of 1 024 + 100: whatever the launcher makes of it (one launch of ragged four-bootstrap workgroups today; a cut into
+    a round and a small launch would show as two kernels), checked at both ends and either side of bootstrap 1 024."""
+    import torch
+    from tfhe_fbs_map_amd.params import choose_params, margin_sigmas, security_bits
+    prm = choose_params(p, norm2, glwe_dims=(1, 2))
+    assert prm.k == 2 and prm.N == 1024 and prm.bsk_group == 2 and prm.l_bsk == 1, "the selector moved: pin this test's parameter set"
+    assert security_bits(prm) >= 127.9 and margin_sigmas(prm, norm2) >= 6.0
+    ctx, o = nat.Context(prm, seed=1), orc.Oracle(prm, seed=1)
+    rng = np.random.default_rng(7 + p)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(16)]
+    tv = ctx.tvset(tables)
+    for B, pick in ((1024, [0, 1, 2, 3, 4, 5, 6, 7, 508, 509, 510, 511, 1020, 1021, 1022, 1023, 301, 778]),
+                    (1124, [0, 3, 1021, 1023, 1024, 1025, 1026, 1027, 1100, 1120, 1121, 1122, 1123])):
+        msgs = rng.integers(0, p, B)
+        ids = (np.arange(B) % 16).astype(np.uint32)
+        cts = ctx.encrypt(msgs, nonce0=100)
+        trivial = [1, 6, 509, 1022, B - 1]
+        for i in trivial:
+            cts[i, :-1] = 0                                          # mask zero: every modulus-switched mask word is zero
+        d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+        d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+        d_out = torch.empty_like(d_in)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, d_out.data_ptr())
+        ctx.sync()
+        launched = [k for k in ctx.profile_kernels() if "blind_rotate" in k]
+        ctx.profile(False)
+        assert "k_blind_rotate_pairs_k2<10,4>" in launched and all("_k2<" in k for k in launched), launched
+        got = d_out.cpu().numpy().view(np.uint64)
+        ref, _ = o.bootstrap_batch(cts[pick], tables, ids[pick])
+        assert np.array_equal(got[pick], ref), (B, launched)
+        keep = np.ones(B, bool)
+        keep[trivial] = False
+        assert np.array_equal(ctx.decrypt(got)[keep], np.array([tables[i][m] for i, m in zip(ids, msgs)])[keep])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,T", [("demo_fbs_exec_env", 2), ("edge_outputs", 5), ("adder8__search_p7", 3), ("aes_sbox__search_p7", 2),
+                                    ("mul16__search_p15", 2)])          # BASELINE config 3's program, every ciphertext
+def test_program_ciphertexts_bit_exact_at_k2(nat, name, T):
+    """Whole programs on a context of GLWE dimension 2 (fbs_eval: k_lincomb on ciphertexts of 2 N + 1 words, the shared key
+    switch, k_blind_rotate_pairs_k2, wire slots) against the oracle evaluating the same instruction list one ciphertext at a
+    time: every output word identical -- tests/test_gpu_parity.py::test_program_ciphertexts_bit_exact at k = 2."""
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture(name)
+    ops, outs = lut_oracle.read_fbs(rec["fbs"])
+    p = max(7, max(len(op[3]) for op in ops if op[0] == "boot"))
+    prm = toy_k2(p)
+    ctx, o = nat.Context(prm, seed=6), orc.Oracle(prm, seed=6)
+    low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
+    ins, expect = subsample(rec, T)
+    cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
+    assert cts.shape[-1] == 2 * 1024 + 1
+    prog = nat.Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                       low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
+    got = prog.eval(cts, T)
+    wires = oracle_eval_program(o, ops, outs, {n: cts[i] for i, n in enumerate(low["input_names"])})
+    for j, (out_name, src) in enumerate(outs):
+        if src in ("0", "1"):
+            assert ctx.decrypt(got[j]).tolist() == [int(src)] * T
+        else:
+            assert np.array_equal(got[j], wires[src]), out_name
+            assert np.array_equal(ctx.decrypt(got[j]), expect[out_name])
     ctx.close()
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import lut_oracle, tfhe_oracle as orc
-from tests.helpers import load_fixture, oracle_eval_program, subsample
+from tests.helpers import load_fixture, oracle_eval_program, subsample, toy_k2
 
 pytestmark = pytest.mark.gpu
 
@@ -20,13 +20,13 @@ def nat():
     return _native
 
 
-def load(nat, toy_params, name, T, seed=6, merge=True):
+def load(nat, toy_params, name, T, seed=6, merge=True, k=1):
     from tfhe_fbs_map_amd import parse_fbs
     rec = load_fixture(name)
     ops, outs = lut_oracle.read_fbs(rec["fbs"])
     tables = [op[3] for op in ops if op[0] == "boot"]
     p = max(7, max(len(t) for t in tables))
-    prm = toy_params.replace(p_msg=p)
+    prm = toy_params.replace(p_msg=p) if k == 1 else toy_k2(p)
     ctx = nat.Context(prm, seed=seed)
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"], merge_linear_prods=merge)
     low = env.lower()
@@ -77,14 +77,23 @@ def test_wire_slots_are_reused(nat, toy_params, name):
     assert len(set(live_outputs)) == len(set(w for w in low["out_wire"] if w >= 0))
 
 
-@pytest.mark.parametrize("name,T", [("adder8__basic_p2", 5), ("adder8__search_p7", 4), ("edge_outputs", 3), ("aes_sbox__basic_p2", 2)])
-def test_levels_in_slices_through_rows_and_back(nat, toy_params, name, T):
+@pytest.mark.parametrize("name,T,k", [("adder8__basic_p2", 5, 1), ("adder8__search_p7", 4, 1), ("edge_outputs", 3, 1), ("aes_sbox__basic_p2", 2, 1),
+                                      ("adder8__search_p7", 4, 2), ("adder8__basic_p2", 5, 2), ("edge_outputs", 3, 2)])
+def test_levels_in_slices_through_rows_and_back(nat, toy_params, name, T, k):
     """Every level cut into three ragged slices (cuts inside a gate's samples and between gates that share a source),
     each slice bootstrapped into a contiguous row buffer and scattered back -- the gate-sharded data path on one GPU
-    -- equals fbs_eval word for word.  The wire buffer has a larger sample stride than the samples in use."""
+    -- equals fbs_eval word for word.  The wire buffer has a larger sample stride than the samples in use.
+    k = 2: the same with GLWE dimension 2 (ciphertexts and rows of 2 N + 1 words), fbs_eval itself held to the oracle."""
     import torch
-    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, name, T)
+    rec, ctx, prm, low, cts, prog, expect, (ops, outs) = load(nat, toy_params, name, T, k=k)
     ref = prog.eval(cts, T)
+    if k == 2:
+        assert prm.k == 2 and prm.ct_words == 2 * prm.N + 1
+        wires_o = oracle_eval_program(orc.Oracle(prm, seed=6), ops, outs, {n: cts[i] for i, n in enumerate(low["input_names"])})
+        for j, (out_name, src) in enumerate(outs):
+            if src not in ("0", "1"):
+                assert np.array_equal(ref[j], wires_o[src]), out_name
+                assert np.array_equal(ctx.decrypt(ref[j]), expect[out_name])
     ctw = prm.ct_words
     stride = T + 2
     wires = torch.zeros((prog.n_slots, stride, ctw), dtype=torch.int64, device="cuda")
@@ -140,12 +149,12 @@ def one_rank_nccl():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,T", [("adder8__search_p7", 5), ("adder8__basic_p2", 4), ("edge_outputs", 3)])
-def test_runners_on_rccl_equal_program_eval(nat, toy_params, one_rank_nccl, name, T):
+@pytest.mark.parametrize("name,T,k", [("adder8__search_p7", 5, 1), ("adder8__basic_p2", 4, 1), ("edge_outputs", 3, 1), ("adder8__search_p7", 5, 2)])
+def test_runners_on_rccl_equal_program_eval(nat, toy_params, one_rank_nccl, name, T, k):
     """GateShardedRunner (send rows -> all_gather_into_tensor -> scatter, forced even with one rank) and
-    SampleShardedRunner on the nccl backend == fbs_eval, word for word."""
+    SampleShardedRunner on the nccl backend == fbs_eval, word for word (k = 2: rows of 2 N + 1 words)."""
     from tfhe_fbs_map_amd.distributed import GateShardedRunner, GpuBackend, SampleShardedRunner
-    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, name, T)
+    rec, ctx, prm, low, cts, prog, expect, _ = load(nat, toy_params, name, T, k=k)
     ref = prog.eval(cts, T)
     const = np.array([w < 0 for w in low["out_wire"]])
     gate = GateShardedRunner(GpuBackend(prog), always_gather=True)

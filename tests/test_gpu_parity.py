@@ -483,7 +483,12 @@ def test_ciphertext_kats_on_the_gpu(nat):
             for i in kat["trivial"]:
                 cts[i, :-1] = 0
             assert digest(cts) == kat["sha256"]["inputs"], name
+            ctx.profile(True)
+            ctx.profile_read(reset=True)
             out = ctx.bootstrap_batch(ctx.tvset(kat["tables"]), cts, np.array(kat["table_ids"], np.uint32))
+            if "four_per_workgroup" in name:                         # the KAT cut for the throughput shape of the k = 2 kernel
+                assert "k_blind_rotate_pairs_k2<10,4>" in ctx.profile_kernels(), ctx.profile_kernels()
+            ctx.profile(False)
             assert digest(out) == kat["sha256"]["outputs"], name
             assert [int(v) for v in ctx.decrypt(out)] == kat["decrypts_to"], name
         else:
@@ -592,6 +597,24 @@ def test_imported_keys_give_the_oracles_ciphertexts(nat, toy_params):
     bad[3] = orc.Q
     with pytest.raises(nat.FbsError, match="canonical"):
         ctx.import_keys(keys["sk_lwe"], keys["sk_glwe"], keys["bsk"], bad)
+    # a key in another layout (here: body and first mask column of every GGSW row exchanged; key-switching rows in [t][kN]
+    # order) is refused by the decryption check of fbs_import_keys instead of bootstrapping to garbage
+    swapped = keys["bsk"].reshape(-1, prm.k + 1, prm.N)[:, ::-1].copy().reshape(-1)
+    with pytest.raises(nat.FbsError, match="does not decrypt"):
+        ctx.import_keys(keys["sk_lwe"], keys["sk_glwe"], swapped, keys["ksk"])
+    transposed = keys["ksk"].reshape(prm.k * prm.N, prm.t_ksk, prm.n + 1).transpose(1, 0, 2).copy().reshape(-1)
+    with pytest.raises(nat.FbsError, match="does not decrypt"):
+        ctx.import_keys(keys["sk_lwe"], keys["sk_glwe"], keys["bsk"], transposed)
+    # ... and the group-2 / k = 2 layout of include/fbs_exec.h (three samples per pair of key bits, rows (comp, level), columns
+    # mask, mask, body) is what the oracle's keys for such a set have: accepted, and the bootstraps are the oracle's
+    from tests.helpers import toy_k2
+    prm2 = toy_k2(7)
+    o2, ctx2 = orc.Oracle(prm2, seed=78), nat.Context(prm2, seed=5, keygen=False)
+    keys2 = o2.keys()
+    ctx2.import_keys(**keys2)
+    cts2 = o2.encrypt(np.arange(7), nonce0=4)
+    assert np.array_equal(ctx2.bootstrap_batch(ctx2.tvset([MODES[0]]), cts2), o2.bootstrap_batch(cts2, [MODES[0]], None)[0])
+    ctx2.close()
     ctx.import_keys(**keys)
     mine = ctx.export_keys()
     assert all(np.array_equal(mine[k], keys[k]) for k in keys)

@@ -173,6 +173,7 @@ def _load():
         "fbs_profile_kernels": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "fbs_sync": (i32, [vp, vp]),
         "fbs_debug_polymul": (i32, [vp, vp, vp, vp]),
+        "fbs_debug_raise": (i32, [vp, i32]),
         "fbs_searcher_create": (i32, [i32, C.POINTER(vp)]),
         "fbs_searcher_destroy": (None, [vp]),
         "fbs_searcher_last_error": (C.c_char_p, [vp]),
@@ -195,7 +196,7 @@ EXPORTED_SYMBOLS = (
     "fbs_program_info",
     "fbs_searcher_create", "fbs_searcher_destroy", "fbs_searcher_last_error", "fbs_searcher_last_kernel_ms",
     "fbs_search_lincomb_coefs", "fbs_eval", "fbs_eval_dev", "fbs_program_layout", "fbs_program_level", "fbs_program_io_slots",
-    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_kernel_catalog", "fbs_profile_kernels", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul",
+    "fbs_level_lincomb_dev", "fbs_level_bootstrap_dev", "fbs_level_scatter_dev", "fbs_profile_enable", "fbs_profile_kernel", "fbs_kernel_catalog", "fbs_profile_kernels", "fbs_profile_read", "fbs_sync", "fbs_debug_polymul", "fbs_debug_raise",
 )
 
 lib = _load()

@@ -695,7 +695,10 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
         hipEvent_t c0, c1;
         prof_begin(ctx, 1, stream, &c0, &c1);
-        if (!launch_blind_rotate_k2(ctx, a, stream, &ctx->prof.kernel[1])) return set_error(ctx, FBS_E_INVALID, "no blind-rotation kernel for this k = 2 shape");
+        if (!launch_blind_rotate_k2(ctx, a, stream, &ctx->prof.kernel[1])) {
+            if (c0) ctx->prof.pool.push_back({c0, c1});   // (the event pair goes back: nothing was recorded between them)
+            return set_error(ctx, FBS_E_INVALID, "no blind-rotation kernel for this k = 2 shape");
+        }
         prof_end(ctx, 1, stream, c0, c1);
         FBS_HIP(ctx, hipGetLastError());
         return FBS_OK;

@@ -172,7 +172,7 @@ static GateView batch_view(const uint64_t *in, uint64_t *out, const uint32_t *ta
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------
-int fbs_poly_size_check(uint32_t poly_size) {
+int fbs_poly_size_check(uint32_t poly_size) try {
     if (poly_size == 0) return set_error(nullptr, FBS_E_INVALID, "polynomial size 0");
     if (poly_size & (poly_size - 1)) {
         uint32_t pow2 = poly_size & (~poly_size + 1);   // largest power of two dividing N
@@ -184,7 +184,7 @@ int fbs_poly_size_check(uint32_t poly_size) {
     if (poly_size < 256 || poly_size > 4096)
         return set_error(nullptr, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048, 4096");
     return FBS_OK;
-}
+} FBS_API_CATCH(nullptr)
 
 static int64_t env_knob(const char *name, int64_t dflt) {
     const char *e = getenv(name);
@@ -258,16 +258,16 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     return FBS_OK;
 }
 
-int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) {
+int fbs_ctx_create(const fbs_params *params, uint64_t seed, int device, fbs_ctx **out) try {
     return ctx_create(params, seed, nullptr, device, out);
-}
+} FBS_API_CATCH(nullptr)
 
-int fbs_ctx_create_seeded(const fbs_params *params, const uint8_t seed[32], int device, fbs_ctx **out) {
+int fbs_ctx_create_seeded(const fbs_params *params, const uint8_t seed[32], int device, fbs_ctx **out) try {
     if (!seed) return set_error(nullptr, FBS_E_INVALID, "null seed");
     return ctx_create(params, 0, seed, device, out);
-}
+} FBS_API_CATCH(nullptr)
 
-int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) {
+int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) try {
     if (!ctx || !knob) return FBS_E_INVALID;
     const std::string k(knob);
     Tune &t = ctx->tune;
@@ -278,22 +278,22 @@ int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) {
     if (value < 0) return set_error(ctx, FBS_E_INVALID, "knob values are non-negative");
     *slot = value;
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_ctx_stat(const fbs_ctx *ctx, const char *name, int64_t *value) {
+int fbs_ctx_stat(const fbs_ctx *ctx, const char *name, int64_t *value) try {
     if (!ctx || !name || !value) return FBS_E_INVALID;
     const std::string k(name);
     if (k == "scratch_growths") *value = ctx->scratch_growths;
     else if (k == "ms_capacity") *value = (int64_t)ctx->ms_capacity;
     else if (k == "acc_capacity") *value = (int64_t)ctx->acc_capacity;
     else if (k == "wires_capacity") *value = (int64_t)ctx->wires_capacity;
-    else if (k == "next_nonce") *value = (int64_t)ctx->next_nonce;
+    else if (k == "next_nonce") *value = (int64_t)ctx->next_nonce.load();
     else if (k == "cu_count") *value = ctx->cu_count;
     else return set_error(ctx, FBS_E_INVALID, "unknown statistic '" + k + "'");
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows, size_t wire_words) {
+int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows, size_t wire_words) try {
     if (!ctx) return FBS_E_INVALID;
     FBS_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -301,9 +301,9 @@ int fbs_ctx_reserve(fbs_ctx *ctx, size_t max_keyswitches, size_t max_shared_rows
     if (max_shared_rows && (rc = ensure_acc(ctx, max_shared_rows)) != FBS_OK) return rc;
     if (wire_words && (rc = ensure_wires(ctx, wire_words)) != FBS_OK) return rc;
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-void fbs_ctx_destroy(fbs_ctx *ctx) {
+void fbs_ctx_destroy(fbs_ctx *ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -323,13 +323,14 @@ void fbs_ctx_destroy(fbs_ctx *ctx) {
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+} catch (...) {   // (nothing here allocates; the promise of the ABI is kept anyway)
 }
 
 const char *fbs_last_error(const fbs_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 const char *fbs_device_info(const fbs_ctx *ctx) { return ctx ? ctx->devinfo.c_str() : ""; }
 
 // ---------------------------------------------------------------------------------------------
-int fbs_keygen(fbs_ctx *ctx) {
+int fbs_keygen(fbs_ctx *ctx) try {
     if (!ctx) return FBS_E_INVALID;
     FBS_HIP(ctx, hipSetDevice(ctx->device));
     host_keygen(ctx);
@@ -337,18 +338,18 @@ int fbs_keygen(fbs_ctx *ctx) {
     if (rc != FBS_OK) return rc;
     ctx->have_keys = true;
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]) {
+int fbs_key_sizes(const fbs_ctx *ctx, size_t sizes[4]) try {
     if (!ctx || !sizes) return FBS_E_INVALID;
     sizes[0] = ctx->p.n;
     sizes[1] = ctx->D;
     sizes[2] = ctx->n_ggsw * ctx->rows * (ctx->p.k + 1) * ctx->N;
     sizes[3] = (size_t)ctx->D * ctx->p.t_ksk * (ctx->p.n + 1);
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk) {
+int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uint64_t *bsk, uint64_t *ksk) try {
     if (!ctx) return FBS_E_INVALID;
     if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
     if (sk_lwe) std::memcpy(sk_lwe, ctx->sk_lwe.data(), ctx->sk_lwe.size() * 8);
@@ -356,9 +357,60 @@ int fbs_export_keys(const fbs_ctx *ctx, uint64_t *sk_lwe, uint64_t *sk_glwe, uin
     if (bsk) std::memcpy(bsk, ctx->bsk.data(), ctx->bsk.size() * 8);
     if (ksk) std::memcpy(ksk, ctx->ksk.data(), ctx->ksk.size() * 8);
     return FBS_OK;
+} FBS_API_CATCH(ctx)
+
+// Do the evaluation keys decrypt under the secrets they came with?  A handful of GGSW samples (every row) and key-switching rows,
+// each phase compared with what the layout of fbs_key_sizes says it encrypts: a key in another sample / row / column order has
+// uniform phases and fails here instead of bootstrapping to garbage.  Tolerance: 16 standard deviations of the set's noise.
+static const char *imported_keys_mismatch(const fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk,
+                                          const uint64_t *ksk) {
+    const fbs_params &p = ctx->p;
+    const uint32_t N = ctx->N, D = ctx->D, n = p.n, k = p.k, l = p.l_bsk, t = p.t_ksk, rows = ctx->rows;
+    auto far = [](uint64_t got, uint64_t want, double tol) { return std::fabs(fq_centered(fq_sub(got, want))) > tol; };
+    const double tol_glwe = 1024.0 + 16.0 * (double)p.sigma_glwe, tol_lwe = 1024.0 + 16.0 * (double)p.sigma_lwe;
+    std::vector<size_t> samples = {0, 1, 2, ctx->n_ggsw / 2, ctx->n_ggsw - 1};
+    std::vector<uint64_t> phase(N);
+    for (size_t g : samples) {
+        if (g >= ctx->n_ggsw) continue;
+        uint64_t bit = sk_lwe[g];
+        if (ctx->group == 2) {
+            const uint64_t s0 = sk_lwe[2 * (g / 3)], s1 = sk_lwe[2 * (g / 3) + 1];
+            bit = g % 3 == 0 ? (s0 & (1 - s1)) : g % 3 == 1 ? ((1 - s0) & s1) : (s0 & s1);
+        }
+        for (uint32_t rr = 0; rr < rows; rr++) {
+            const uint32_t comp = rr / l, lv = rr % l;
+            const uint64_t *row = bsk + (g * rows + rr) * (size_t)(k + 1) * N;
+            for (uint32_t j = 0; j < N; j++) phase[j] = row[(size_t)k * N + j];
+            for (uint32_t c = 0; c < k; c++)                            // phase -= A_c * S_c (negacyclic, binary S)
+                for (uint32_t sh = 0; sh < N; sh++) {
+                    if (!sk_glwe[(size_t)c * N + sh]) continue;
+                    const uint64_t *a = row + (size_t)c * N;
+                    for (uint32_t j = 0; j < N - sh; j++) phase[j + sh] = fq_sub(phase[j + sh], a[j]);
+                    for (uint32_t j = N - sh; j < N; j++) phase[j + sh - N] = fq_add(phase[j + sh - N], a[j]);
+                }
+            // row (comp, lv) = GLWE(0) + bit g_lv on component comp: the phase is bit g_lv at X^0 (body row), -bit g_lv S_comp (mask rows)
+            for (uint32_t j = 0; j < N; j++) {
+                uint64_t want = 0;
+                if (bit && comp == k && j == 0) want = ctx->g[lv];
+                if (bit && comp < k && sk_glwe[(size_t)comp * N + j]) want = fq_sub(0, ctx->g[lv]);
+                if (far(phase[j], want, tol_glwe)) return "bootstrapping key does not decrypt under the supplied secrets (sample / row / column order of fbs_key_sizes?)";
+            }
+        }
+    }
+    const size_t ksk_rows = (size_t)D * t;
+    for (size_t r : {(size_t)0, (size_t)1, (size_t)2, (size_t)3, ksk_rows / 2, ksk_rows - 4, ksk_rows - 3, ksk_rows - 2, ksk_rows - 1}) {
+        if (r >= ksk_rows) continue;
+        const uint32_t j = (uint32_t)(r / t), v = (uint32_t)(r % t);
+        const uint64_t *row = ksk + r * (size_t)(n + 1);
+        uint64_t ph = row[n];
+        for (uint32_t i = 0; i < n; i++)
+            if (sk_lwe[i]) ph = fq_sub(ph, row[i]);
+        if (far(ph, sk_glwe[j] ? ctx->h[v] : 0, tol_lwe)) return "key-switching key does not decrypt under the supplied secrets (row order [kN][t][n+1]?)";
+    }
+    return nullptr;
 }
 
-int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk, const uint64_t *ksk) {
+int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glwe, const uint64_t *bsk, const uint64_t *ksk) try {
     if (!ctx) return FBS_E_INVALID;
     if (!sk_lwe || !sk_glwe || !bsk || !ksk) return set_error(ctx, FBS_E_INVALID, "null argument");
     FBS_HIP(ctx, hipSetDevice(ctx->device));
@@ -372,6 +424,7 @@ int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glw
         if (bsk[i] >= FQ) return set_error(ctx, FBS_E_INVALID, "bootstrapping-key word is not a canonical residue");
     for (size_t i = 0; i < sizes[3]; i++)
         if (ksk[i] >= FQ) return set_error(ctx, FBS_E_INVALID, "key-switching-key word is not a canonical residue");
+    if (const char *why = imported_keys_mismatch(ctx, sk_lwe, sk_glwe, bsk, ksk)) return set_error(ctx, FBS_E_INVALID, why);
     if (ctx->scratch_used) FBS_HIP(ctx, hipStreamSynchronize(ctx->scratch_stream));   // kernels may still read the old keys
     ctx->sk_lwe.assign(sk_lwe, sk_lwe + sizes[0]);
     ctx->sk_glwe.assign(sk_glwe, sk_glwe + sizes[1]);
@@ -382,39 +435,45 @@ int fbs_import_keys(fbs_ctx *ctx, const uint64_t *sk_lwe, const uint64_t *sk_glw
     if (rc != FBS_OK) return rc;
     ctx->have_keys = true;
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_encrypt_fresh(fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t *cts, uint64_t *nonce0) {
+int fbs_encrypt_fresh(fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t *cts, uint64_t *nonce0) try {
     if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
     if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
-    if (ctx->next_nonce + count > (1ull << 56)) return set_error(ctx, FBS_E_STATE, "encryption streams of this context are used up");
-    const uint64_t first = ctx->next_nonce;
-    ctx->next_nonce += count;
+    // the range [first, first + count) is reserved atomically: two threads encrypting on one context never share a stream (the
+    // bound is checked BEFORE the counter moves, so a refused call leaves it where it was)
+    uint64_t first = ctx->next_nonce.load(std::memory_order_relaxed);
+    do {
+        if (count > (1ull << 56) || first + count > (1ull << 56)) return set_error(ctx, FBS_E_STATE, "encryption streams of this context are used up");
+    } while (!ctx->next_nonce.compare_exchange_weak(first, first + count, std::memory_order_relaxed));
     if (nonce0) *nonce0 = first;
     host_encrypt(ctx, msgs, count, first, cts);
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts) {
+int fbs_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts) try {
     if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
     if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
     // streams [2^55, 2^56) belong to fbs_encrypt_fresh: an explicit nonce can never repeat one the context handed out itself
     if (nonce0 >= (1ull << 55) || count > (1ull << 55) - nonce0) return set_error(ctx, FBS_E_INVALID, "nonce0 + count must stay below 2^55");
     host_encrypt(ctx, msgs, count, nonce0, cts);
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs) {
+int fbs_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs) try {
     if (!ctx || (count && (!msgs || !cts))) return FBS_E_INVALID;
     if (!ctx->have_keys) return set_error(ctx, FBS_E_STATE, "fbs_keygen has not run");
     host_decrypt(ctx, cts, count, msgs);
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
-int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *table_off, uint32_t n_tables, fbs_tvset **out) {
+int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *table_off, uint32_t n_tables, fbs_tvset **out) try {
     if (!ctx || !out || (n_tables && (!table_vals || !table_off))) return FBS_E_INVALID;
     *out = nullptr;
+    // the count is checked BEFORE anything is sized by it: more than 2^20 tables (8 GB of test vectors at N = 1024) is a
+    // corrupted count, not a program
+    if (n_tables > FBS_MAX_TABLES) return set_error(ctx, FBS_E_INVALID, "more than FBS_MAX_TABLES tables");
     FBS_HIP(ctx, hipSetDevice(ctx->device));
     std::unique_ptr<fbs_tvset> tv(new fbs_tvset);
     tv->ctx = ctx;
@@ -460,16 +519,16 @@ int fbs_tvset_create(fbs_ctx *ctx, const int32_t *table_vals, const uint32_t *ta
     }
     *out = tv.release();
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_table_fusion_norms(const fbs_tvset *tv, uint32_t table, uint64_t *d_norm2, uint64_t *g_norm2) {
+int fbs_table_fusion_norms(const fbs_tvset *tv, uint32_t table, uint64_t *d_norm2, uint64_t *g_norm2) try {
     if (!tv || table >= tv->n_tables) return FBS_E_INVALID;
     if (d_norm2) *d_norm2 = tv->diff_norm2[table];
     if (g_norm2) *g_norm2 = tv->g_norm2[table];
     return FBS_OK;
-}
+} FBS_API_CATCH(tv ? tv->ctx : nullptr)
 
-void fbs_tvset_destroy(fbs_tvset *tv) {
+void fbs_tvset_destroy(fbs_tvset *tv) try {
     if (!tv) return;
     if (tv->ctx) (void)hipSetDevice(tv->ctx->device);
     if (tv->d_tvs) (void)hipFree(tv->d_tvs);
@@ -478,6 +537,7 @@ void fbs_tvset_destroy(fbs_tvset *tv) {
     if (tv->d_diff_val) (void)hipFree(tv->d_diff_val);
     if (tv->d_diff_n) (void)hipFree(tv->d_diff_n);
     delete tv;
+} catch (...) {   // (nothing here allocates; the promise of the ABI is kept anyway)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,7 +550,7 @@ static int check_ready(fbs_ctx *ctx, const fbs_tvset *tv) {
 }
 
 int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_cts_in, const uint32_t *d_table_ids,
-                            size_t count, uint64_t *d_cts_out, void *stream) {
+                            size_t count, uint64_t *d_cts_out, void *stream) try {
     int rc = check_ready(ctx, tv);
     if (rc != FBS_OK) return rc;
     if (!tv || (count && (!d_cts_in || !d_cts_out))) return set_error(ctx, FBS_E_INVALID, "null argument");
@@ -506,10 +566,10 @@ int fbs_bootstrap_batch_dev(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d
     rc = dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
     if (rc != FBS_OK) return scratch_fail(ctx, s, rc);
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
 int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_in, const uint32_t *table_ids, size_t count,
-                        uint64_t *cts_out) {
+                        uint64_t *cts_out) try {
     int rc = check_ready(ctx, tv);
     if (rc != FBS_OK) return rc;
     if (!tv || (count && (!cts_in || !cts_out))) return set_error(ctx, FBS_E_INVALID, "null argument");
@@ -543,7 +603,7 @@ int fbs_bootstrap_batch(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *cts_i
     FBS_HIP(ctx, hipMemcpyAsync(cts_out, ctx->d_stage_out, words * 8, hipMemcpyDeviceToHost, s));
     FBS_HIP(ctx, hipStreamSynchronize(s));
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
 // wire-slot building blocks with HOST index arrays (convenience: each call stages its indices through a
@@ -563,7 +623,7 @@ static int ensure_idx(fbs_ctx *ctx, size_t words) {
 }
 
 int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, const uint32_t *dst, const uint32_t *term_off,
-                    const uint32_t *srcs, const int64_t *coefs, const int64_t *consts, void *stream) {
+                    const uint32_t *srcs, const int64_t *coefs, const int64_t *consts, void *stream) try {
     int rc = check_ready(ctx, nullptr);
     if (rc != FBS_OK) return rc;
     if (n_out == 0 || T == 0) return FBS_OK;
@@ -592,11 +652,11 @@ int fbs_lincomb_dev(fbs_ctx *ctx, uint64_t *d_wires, size_t T, uint32_t n_out, c
     rc = dev_lincomb(ctx, d_wires, T, 0, T, n_out, d_dst, d_off, d_srcs, d_f, d_f + n_terms, s);
     if (rc != FBS_OK) return rc;
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
 int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires, size_t T, uint32_t n_gates,
                             const uint32_t *src, const uint32_t *dst, const uint32_t *table_ids, size_t s_begin, size_t s_end,
-                            void *stream) {
+                            void *stream) try {
     int rc = check_ready(ctx, tv);
     if (rc != FBS_OK) return rc;
     if (!tv || !d_wires || !src || !dst || !table_ids) return set_error(ctx, FBS_E_INVALID, "null argument");
@@ -636,22 +696,28 @@ int fbs_bootstrap_wires_dev(fbs_ctx *ctx, const fbs_tvset *tv, uint64_t *d_wires
     rc = dev_blind_rotate(ctx, tv, gv, ctx->d_ms, s);
     if (rc != FBS_OK) return rc;
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
 // whole-program executor
 // ---------------------------------------------------------------------------------------------
-int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, fbs_prog **out) {
+int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, fbs_prog **out) try {
     return fbs_program_load_ex(ctx, d, tv, 0, out);
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, uint32_t flags, fbs_prog **out) {
+int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset *tv, uint32_t flags, fbs_prog **out) try {
     int rc = check_ready(ctx, tv);
     if (rc != FBS_OK) return rc;
     if (!d || !out) return set_error(ctx, FBS_E_INVALID, "null argument");
     *out = nullptr;
     if (flags & ~(uint32_t)FBS_LOAD_FUSE_TABLES) return set_error(ctx, FBS_E_INVALID, "unknown load flag");
     if ((flags & FBS_LOAD_FUSE_TABLES) && ctx->p.k != 1) return set_error(ctx, FBS_E_INVALID, "shared rotations (FBS_LOAD_FUSE_TABLES) are built for k = 1");
+    // counts are checked BEFORE anything is sized by them (wire ids are 32-bit: n_inputs + n_instr must not wrap)
+    if ((uint64_t)d->n_inputs + d->n_instr > FBS_MAX_WIRES || d->n_terms > FBS_MAX_TERMS || d->n_outputs > FBS_MAX_WIRES)
+        return set_error(ctx, FBS_E_INVALID, "program too large: n_inputs + n_instr and n_outputs are bounded by FBS_MAX_WIRES, n_terms by FBS_MAX_TERMS");
+    if ((d->n_instr && (!d->kind || !d->arg0 || !d->arg1 || !d->const_coef)) || (d->n_terms && (!d->term_coef || !d->term_src)) ||
+        (d->n_outputs && !d->out_wire))
+        return set_error(ctx, FBS_E_INVALID, "null array in the program description");
     std::unique_ptr<fbs_prog, void (*)(fbs_prog *)> prog(new fbs_prog, fbs_program_destroy);
     prog->fused = (flags & FBS_LOAD_FUSE_TABLES) != 0;
     prog->ctx = ctx;
@@ -851,24 +917,25 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
     }
     *out = prog.release();
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-void fbs_program_destroy(fbs_prog *prog) {
+void fbs_program_destroy(fbs_prog *prog) try {
     if (!prog) return;
     if (prog->ctx) (void)hipSetDevice(prog->ctx->device);
     for (void *p : prog->allocations) (void)hipFree(p);
     delete prog;
+} catch (...) {   // (nothing here allocates; the promise of the ABI is kept anyway)
 }
 
-int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap) {
+int fbs_program_info(const fbs_prog *prog, uint32_t *n_levels, uint32_t *max_width, uint32_t *n_bootstrap) try {
     if (!prog) return FBS_E_INVALID;
     if (n_levels) *n_levels = prog->depth;
     if (max_width) *max_width = prog->max_width;
     if (n_bootstrap) *n_bootstrap = prog->n_bootstrap;
     return FBS_OK;
-}
+} FBS_API_CATCH(prog ? prog->ctx : nullptr)
 
-int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) {
+int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) try {
     if (!prog || !out) return FBS_E_INVALID;
     out->n_slots = prog->n_slots;
     out->n_levels = prog->depth;
@@ -881,21 +948,21 @@ int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) {
     out->n_inputs = prog->n_inputs;
     out->n_outputs = prog->n_outputs;
     return FBS_OK;
-}
+} FBS_API_CATCH(prog ? prog->ctx : nullptr)
 
-int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources) {
+int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources) try {
     if (!prog || level >= prog->depth) return FBS_E_INVALID;
     if (n_gates) *n_gates = prog->boot[level].n_gates;
     if (n_sources) *n_sources = prog->boot[level].n_sources;
     return FBS_OK;
-}
+} FBS_API_CATCH(prog ? prog->ctx : nullptr)
 
-int fbs_program_io_slots(const fbs_prog *prog, uint32_t *in_slot, int64_t *out_slot) {
+int fbs_program_io_slots(const fbs_prog *prog, uint32_t *in_slot, int64_t *out_slot) try {
     if (!prog) return FBS_E_INVALID;
     if (in_slot) std::copy(prog->in_slot.begin(), prog->in_slot.end(), in_slot);
     if (out_slot) std::copy(prog->out_slot.begin(), prog->out_slot.end(), out_slot);
     return FBS_OK;
-}
+} FBS_API_CATCH(prog ? prog->ctx : nullptr)
 
 // ---- one level at a time, device-resident wires, nothing but kernel launches on `stream` ------------------------
 static int check_level_call(fbs_ctx *ctx, const fbs_prog *prog, const uint64_t *d_wires, size_t T, size_t s_begin, size_t s_count) {
@@ -908,7 +975,7 @@ static int check_level_call(fbs_ctx *ctx, const fbs_prog *prog, const uint64_t *
 }
 
 int fbs_level_lincomb_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
-                          size_t s_count, void *stream) {
+                          size_t s_count, void *stream) try {
     int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
     if (rc != FBS_OK) return rc;
     if (level > prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
@@ -918,10 +985,10 @@ int fbs_level_lincomb_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
         if (rc != FBS_OK) return rc;
     }
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
 int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
-                            size_t s_count, size_t f_begin, size_t f_end, uint64_t *d_rows, void *stream) {
+                            size_t s_count, size_t f_begin, size_t f_end, uint64_t *d_rows, void *stream) try {
     int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
     if (rc != FBS_OK) return rc;
     if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
@@ -973,10 +1040,10 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
         (rc = dev_multi_extract(ctx, prog->tv, ctx->d_acc, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_row, b.d_x_table, b.d_x_dst, s)) != FBS_OK)
         return scratch_fail(ctx, s, rc);
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
 int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, uint64_t *d_wires, size_t T, size_t s_begin,
-                          size_t s_count, const uint64_t *d_rows, size_t f_begin, size_t f_end, void *stream) {
+                          size_t s_count, const uint64_t *d_rows, size_t f_begin, size_t f_end, void *stream) try {
     int rc = check_level_call(ctx, prog, d_wires, T, s_begin, s_count);
     if (rc != FBS_OK) return rc;
     if (level >= prog->depth) return set_error(ctx, FBS_E_INVALID, "level out of range");
@@ -990,7 +1057,7 @@ int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
     if (rc != FBS_OK || !b.n_shared) return rc;
     return dev_multi_extract(ctx, prog->tv, d_rows, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_gate, b.d_x_table, b.d_x_dst,
                              pick(ctx, stream));
-}
+} FBS_API_CATCH(ctx)
 
 static int run_levels(fbs_ctx *ctx, const fbs_prog *prog, uint64_t *d_wires, size_t T, size_t s_count, hipStream_t s) {
     int rc;
@@ -1027,7 +1094,7 @@ static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *c
 
 static uint64_t trivial_body(const fbs_ctx *ctx, int64_t out_slot) { return fq_mul(fq_from_i64(-1 - out_slot), 2 * ctx->delta_half); }
 
-int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, uint64_t *d_out, void *stream) {
+int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, uint64_t *d_out, void *stream) try {
     int rc = check_ready(ctx, prog ? prog->tv : nullptr);
     if (rc != FBS_OK) return rc;
     if (!prog || prog->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "program belongs to another context");
@@ -1051,9 +1118,9 @@ int fbs_eval_dev(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *d_in, size_t T, u
         }
     }
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts) {
+int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uint64_t *out_cts) try {
     int rc = check_ready(ctx, prog ? prog->tv : nullptr);
     if (rc != FBS_OK) return rc;
     if (!prog || prog->ctx != ctx) return set_error(ctx, FBS_E_INVALID, "program belongs to another context");
@@ -1086,14 +1153,14 @@ int fbs_eval(fbs_ctx *ctx, fbs_prog *prog, const uint64_t *in_cts, size_t T, uin
         FBS_HIP(ctx, hipStreamSynchronize(s));
     }
     return scratch_done(ctx, s);
-}
+} FBS_API_CATCH(ctx)
 
 // ---------------------------------------------------------------------------------------------
-int fbs_profile_enable(fbs_ctx *ctx, int on) {
+int fbs_profile_enable(fbs_ctx *ctx, int on) try {
     if (!ctx) return FBS_E_INVALID;
     ctx->prof.on = on != 0;
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
 static int profile_collect(fbs_ctx *ctx) {
     FBS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1114,7 +1181,7 @@ static int profile_collect(fbs_ctx *ctx) {
     return FBS_OK;
 }
 
-int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset) {
+int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset) try {
     if (!ctx) return FBS_E_INVALID;
     if (int rc = profile_collect(ctx)) return rc;
     for (int k = 0; k < 3; k++) {
@@ -1127,9 +1194,9 @@ int fbs_profile_read(fbs_ctx *ctx, double ms[3], uint64_t launches[3], int reset
         }
     }
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_profile_kernels(fbs_ctx *ctx, char *buf, size_t cap, size_t *needed) {
+int fbs_profile_kernels(fbs_ctx *ctx, char *buf, size_t cap, size_t *needed) try {
     if (!ctx) return FBS_E_INVALID;
     if (int rc = profile_collect(ctx)) return rc;
     std::string text;
@@ -1143,14 +1210,14 @@ int fbs_profile_kernels(fbs_ctx *ctx, char *buf, size_t cap, size_t *needed) {
     if (!buf || cap < text.size() + 1) return buf ? set_error(ctx, FBS_E_INVALID, "buffer too small") : FBS_OK;
     std::memcpy(buf, text.c_str(), text.size() + 1);
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-const char *fbs_profile_kernel(const fbs_ctx *ctx, int which) {
+const char *fbs_profile_kernel(const fbs_ctx *ctx, int which) try {
     if (!ctx || which < 0 || which > 2) return "";
     return ctx->prof.kernel[which].c_str();
-}
+} catch (...) { return ""; }
 
-const char *fbs_kernel_catalog(void) {
+const char *fbs_kernel_catalog(void) try {
     static const std::string text = [] {
         std::vector<std::string> names;
         keyswitch_catalog(&names);
@@ -1160,16 +1227,16 @@ const char *fbs_kernel_catalog(void) {
         return t;
     }();
     return text.c_str();
-}
+} catch (...) { return ""; }
 
-int fbs_sync(fbs_ctx *ctx, void *stream) {
+int fbs_sync(fbs_ctx *ctx, void *stream) try {
     if (!ctx) return FBS_E_INVALID;
     FBS_HIP(ctx, hipSetDevice(ctx->device));
     FBS_HIP(ctx, hipStreamSynchronize(pick(ctx, stream)));
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
 
-int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c) {
+int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64_t *c) try {
     int rc = check_ready(ctx, nullptr);
     if (rc != FBS_OK) return rc;
     const size_t bytes = (size_t)ctx->N * 8;
@@ -1186,6 +1253,16 @@ int fbs_debug_polymul(fbs_ctx *ctx, const uint64_t *a, const uint64_t *b, uint64
     if (rc != FBS_OK) return rc;
     if (e != hipSuccess) return set_error(ctx, FBS_E_DEVICE, std::string("polymul: ") + hipGetErrorString(e));
     return FBS_OK;
-}
+} FBS_API_CATCH(ctx)
+
+// test hook: raise inside an entry point what a host allocation or a library call could raise, to show the barrier holds
+// (kind 0: std::bad_alloc, 1: std::length_error, 2: std::runtime_error, 3: a non-standard exception; anything else: no throw)
+int fbs_debug_raise(fbs_ctx *ctx, int kind) try {
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) throw std::length_error("vector::_M_default_append");
+    if (kind == 2) throw std::runtime_error("raised on request");
+    if (kind == 3) throw 42;
+    return FBS_OK;
+} FBS_API_CATCH(ctx)
 
 }  // extern "C"

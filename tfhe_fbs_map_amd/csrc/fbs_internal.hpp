@@ -3,8 +3,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -97,7 +100,7 @@ struct fbs_ctx {
     fbs_params p{};
     uint64_t seed = 0;
     fbs::RandKey rkey{};               // what all randomness of the context is expanded from
-    uint64_t next_nonce = 1ull << 55;  // fbs_encrypt_fresh: first unused encryption stream of [2^55, 2^56)
+    std::atomic<uint64_t> next_nonce{1ull << 55};  // fbs_encrypt_fresh: first unused encryption stream of [2^55, 2^56); reserved by compare-exchange
     fbs::Tune tune;
     int64_t scratch_growths = 0;       // how often a call had to (re)allocate scratch, i.e. blocked (fbs_ctx_stat)
     int device = 0;
@@ -175,6 +178,41 @@ int set_error(const fbs_ctx *ctx, int code, const std::string &msg);
         if (e__ != hipSuccess)                                                                   \
             return fbs::set_error(ctx, FBS_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// The ABI promises "never throws, never aborts" (include/fbs_exec.h): every extern "C" entry point is a function-try-block that
+// ends in FBS_API_CATCH(owner of the error text).  translate_exception re-throws the exception in flight and maps it: an
+// allocation the host cannot serve (a std::vector or std::thread sized by caller input) -> FBS_E_NOMEM, anything else ->
+// FBS_E_INVALID with its what().  `report` is set_error or the searcher's equivalent; it may itself fail to allocate the text.
+template <class Report>
+int translate_exception(Report &&report) noexcept {
+    int code = FBS_E_INVALID;
+    const char *text = "unknown internal error";
+    std::string what;
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = FBS_E_NOMEM, text = "out of host memory";
+    } catch (const std::length_error &) {
+        code = FBS_E_NOMEM, text = "out of host memory (a size computed from the arguments exceeds what a container can hold)";
+    } catch (const std::exception &e) {
+        try {
+            what = std::string("internal error: ") + e.what();
+            text = what.c_str();
+        } catch (...) {
+        }
+    } catch (...) {
+    }
+    try {
+        report(code, text);
+    } catch (...) {
+    }
+    return code;
+}
+#define FBS_API_CATCH(owner)                                                                                          \
+    catch (...) {                                                                                                     \
+        const fbs_ctx *owner__ = (owner);                                                                             \
+        return fbs::translate_exception([&](int code, const char *text) { fbs::set_error(owner__, code, text); });    \
+    }
 
 // host side (fbs_host.cpp)
 void host_keygen(fbs_ctx *ctx);

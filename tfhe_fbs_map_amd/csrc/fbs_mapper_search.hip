@@ -146,9 +146,16 @@ static int search_error(const fbs_searcher *s, int code, const std::string &msg)
         if (e__ != hipSuccess) return search_error(s, FBS_E_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// (the exception barrier of the ABI: fbs_internal.hpp, translate_exception)
+#define SEARCH_API_CATCH(owner)                                                                                  \
+    catch (...) {                                                                                                \
+        const fbs_searcher *owner__ = (owner);                                                                   \
+        return fbs::translate_exception([&](int code, const char *text) { search_error(owner__, code, text); }); \
+    }
+
 extern "C" {
 
-int fbs_searcher_create(int device, fbs_searcher **out) {
+int fbs_searcher_create(int device, fbs_searcher **out) try {
     if (!out) return FBS_E_INVALID;
     *out = nullptr;
     int n_dev = 0;
@@ -165,9 +172,9 @@ int fbs_searcher_create(int device, fbs_searcher **out) {
     }
     *out = s;
     return FBS_OK;
-}
+} SEARCH_API_CATCH(nullptr)
 
-void fbs_searcher_destroy(fbs_searcher *s) {
+void fbs_searcher_destroy(fbs_searcher *s) try {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->d_rows) (void)hipFree(s->d_rows);
@@ -176,13 +183,14 @@ void fbs_searcher_destroy(fbs_searcher *s) {
     if (s->e1) (void)hipEventDestroy(s->e1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
+} catch (...) {
 }
 
 const char *fbs_searcher_last_error(const fbs_searcher *s) { return s ? s->err.c_str() : g_search_error.c_str(); }
 double fbs_searcher_last_kernel_ms(const fbs_searcher *s) { return s ? s->last_kernel_ms : 0.0; }
 
 int fbs_search_lincomb_coefs(fbs_searcher *s, const int32_t *x, const int32_t *y, const uint8_t *tt, uint32_t rows,
-                             uint32_t fbs_size, uint32_t max_fbs_size, int32_t ab[2], int64_t *mvt, int *found) {
+                             uint32_t fbs_size, uint32_t max_fbs_size, int32_t ab[2], int64_t *mvt, int *found) try {
     if (!s || !x || !y || !tt || !ab || !found) return FBS_E_INVALID;
     *found = 0;
     if (rows == 0) return search_error(s, FBS_E_INVALID, "no rows");
@@ -274,6 +282,6 @@ int fbs_search_lincomb_coefs(fbs_searcher *s, const int32_t *x, const int32_t *y
     if (mvt)
         for (uint32_t r = 0; r < rows; r++) mvt[r] = (int64_t)ab[0] * x[r] + (int64_t)ab[1] * y[r];
     return FBS_OK;
-}
+} SEARCH_API_CATCH(s)
 
 }  // extern "C"

@@ -168,7 +168,7 @@ class ExecConfig:
         stats = env.stats()
         wide = False
         if samples and 2 in self.glwe_dims and stats["nb_bootstrap"]:
-            from .distributed import plan_levels
+            from .schedule import plan_levels
             depth = max(1, plan_levels(env.lower())["depth"])
             wide = stats["nb_bootstrap"] * int(samples) >= self.wide_level * depth
         fstats = env.fusion_stats(p) if self.fuse_tables is not False else None

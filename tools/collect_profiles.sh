@@ -22,6 +22,7 @@ rec p31g1 766 1 1024
 rec p63 822 1 1024
 rec p4 638 1 1024
 rec securek2 734 2 1024
+rec p4k2 630 2 1024
 rec secure256 714 2 256
 rec p31cu 766 2 256
 rec lean512 630 1 512

@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 DEFAULT = [r"k_blind_rotate<10, 6, 3, 4, true>", r"k_blind_rotate<10, 6, 3, 1, true>", r"k_blind_rotate<10, 6, 6, 1, true>",
            r"k_blind_rotate<11, 7, 4, 1, true>", r"k_blind_rotate<11, 7, 5, 1, true>", r"k_blind_rotate<12, 8, 5, 1, true>",
            r"k_blind_rotate_pairs<11, 7, 4>", r"k_blind_rotate_cu<10, 3, 2, false>", r"k_blind_rotate_cu<10, 3, 2, true>",
-           r"k_blind_rotate_cu_pairs<11, 1>", r"k_blind_rotate_cu_pairs<11, 2>", r"k_blind_rotate_pairs_k2<10>"]
+           r"k_blind_rotate_cu_pairs<11, 1>", r"k_blind_rotate_cu_pairs<11, 2>", r"k_blind_rotate_pairs_k2<10, 4>"]
 
 
 def demangle(names):

@@ -1,5 +1,6 @@
 """Race hunt for the whole-CU kernels: every launch shape that shares LDS words between phases (hand-over = inverse exchange =
-re-deal in k_blind_rotate_cu_pairs; accumulator words = hand-over in k_blind_rotate_cu) is run REPS times on the same inputs at
+re-deal in k_blind_rotate_cu_pairs; accumulator words = hand-over in k_blind_rotate_cu; exchange buffer = landing words of the LDS
+atomics in the k = 2 kernels) is run REPS times on the same inputs at
 full n, with every CU busy, and every run must give the first run's ciphertexts bit for bit; the first run is checked against the
 expected cleartexts.  A race shows as a rare mismatch.   python3 tools/soak_determinism.py [reps = 40]"""
 import os, sys
@@ -11,7 +12,12 @@ from tfhe_fbs_map_amd import Context, P1024, choose_params
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 CASES = [("P1024", P1024, (64, 256, 300, 512)), ("p15 128-bit", choose_params(15, 70), (256, 200)),
          ("p31 128-bit", choose_params(31, 325), (256, 300, 1024)), ("p31 one key bit", choose_params(31, 325, groups=(1,)), (256,)),
-         ("p4 128-bit", choose_params(4, 2), (256, 512))]
+         ("p4 128-bit", choose_params(4, 2), (256, 512)),
+         # GLWE dimension 2: every wave of a bootstrap clears its exchange buffer, all three ADD their products into it with LDS
+         # atomics and read the total back, between two barriers per step (csrc/fbs_blind_rotate_k2.hip) -- one, two and four
+         # bootstraps per workgroup
+         ("p15 128-bit k=2", choose_params(15, 70, glwe_dims=(1, 2)), (200, 256, 300, 512, 1024, 1124)),
+         ("p4 128-bit k=2", choose_params(4, 2, glwe_dims=(1, 2)), (256, 1024))]
 bad = 0
 for label, prm, sizes in CASES:
     ctx = Context(prm, seed=5)
