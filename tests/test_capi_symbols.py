@@ -135,7 +135,7 @@ def test_absurd_counts_come_back_as_codes():
     import numpy as np
     from tfhe_fbs_map_amd import Params, _native as nat
     lib = nat.lib
-    ctx = nat.Context(Params(n=8, log_n_poly=8, p_msg=7), seed=1)
+    ctx = nat.Context(Params(n=8, log_n_poly=8, p_msg=7, sigma_lwe=1 << 6, sigma_glwe=1 << 4), seed=1)
     tv = ctx.tvset([[0, 1, 1, 0]])
     one8, one32, one64 = np.zeros(4, np.uint8), np.zeros(4, np.uint32), np.zeros(4, np.int64)
 

@@ -81,7 +81,7 @@ def test_the_stub_compiles_and_reads_only_the_reference_surface():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,fbs_size,T", [("demo_fbs_exec_env", 4, 2), ("full_adder__search_p7", 7, 24), ("adder8__basic_p2", 2, 16),
+@pytest.mark.parametrize("name,fbs_size,T", [("demo_fbs_exec_env", 4, 2), ("full_adder__search_p7", 7, 24), ("adder8__basic_p2", 4, 16),
                                              ("aes_sbox__search_p3", 3, 16), ("mul4__search_p15", 15, 8)])
 def test_the_stub_evaluates_reference_programs_on_the_gpu(name, fbs_size, T):
     """The pasted method, run: same dict in, same dict out as the reference's cleartext `eval` (its goldens)."""

@@ -567,7 +567,8 @@ static int upload_keys_t(fbs_ctx *ctx) {
         constexpr int LLS = lanes_log2_for_small_launch(LOGN);
         if constexpr (LLS != LL) {
             // (two key bits per step: a second copy of the 1.5 times larger key only where a kernel reads it -- N = 2048, l <= 2)
-            if (ctx->group == 1 || (LOGN == 11 && ctx->p.l_bsk <= 2)) {
+            // (... and N = 1024 at GLWE dimension 2: the whole-workgroup latency shapes of fbs_blind_rotate_k2.hip)
+            if (ctx->group == 1 || (LOGN == 11 && ctx->p.l_bsk <= 2) || (LOGN == 10 && ctx->p.k == 2)) {
                 if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
                 if (e == hipSuccess) {
                     hipLaunchKernelGGL((k_bsk_transform<LOGN, LLS>), dim3(grid), dim3(1 << LLS), 0, ctx->stream, d_src,
@@ -575,6 +576,16 @@ static int upload_keys_t(fbs_ctx *ctx) {
                                        n_inv, polys);
                     e = hipGetLastError();
                 }
+            }
+        }
+    }
+    if constexpr (LOGN == 10) {
+        if (e == hipSuccess && ctx->p.k == 2 && ctx->tune.br_k2_mid_copy) {   // (a third copy, for the six-wave shape: experiments)
+            if (!ctx->d_bsk_hat_mid) e = hipMalloc(&ctx->d_bsk_hat_mid, polys * N * 8);
+            if (e == hipSuccess) {
+                launch_bsk_transform_two_waves(d_src, reinterpret_cast<double *>(ctx->d_bsk_hat_mid), reinterpret_cast<const double *>(ctx->d_tw_fwd),
+                                               fq_centered(fq_inv(N)), polys, ctx->stream);
+                e = hipGetLastError();
             }
         }
     }

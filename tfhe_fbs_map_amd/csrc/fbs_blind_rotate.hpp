@@ -81,5 +81,7 @@ void blind_rotate_cu_catalog(std::vector<std::string> *out);
 // four bootstraps per workgroup.  Returns false when the context is not of that shape.
 bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_k2_catalog(std::vector<std::string> *out);
+// ... and the key transform into the evaluation order of its six-wave latency shape (WavesNtt<10, 1>)
+void launch_bsk_transform_two_waves(const uint64_t *d_src, double *d_dst, const double *tw_fwd, double n_inv, size_t polys, hipStream_t stream);
 
 }  // namespace fbs
