@@ -83,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sharded-legs", action="store_true", help="batch, --gpus > 1: skip the gate- and sample-sharded circuit legs")
     ap.add_argument("--sharded-circuit", default="trivium_stream_v2__search_p15", help="batch, --gpus > 1: the circuit of those legs")
     ap.add_argument("--sharded-samples", type=int, default=64, help="... and its samples")
+    ap.add_argument("--sharded-reduced-noise", action="store_true", help="... on the reduced-noise benchmark set instead of the 128-bit set chosen for the circuit")
     ap.add_argument("--circuit", default="trivium_stream_v2__search_p15", help="circuit: fixture under tests/golden")
     ap.add_argument("--samples", type=int, default=64, help="circuit: samples per input (per rank in mode sample)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="FBS timed on the host CPU (-1: 64 per thread, 0: skip)")
@@ -163,7 +164,7 @@ def worker(args):
             dist.destroy_process_group()
         return 3
     if args.workload == "batch" and world > 1 and not args.no_sharded_legs:
-        sharded = sharded_legs(rank, world, local, dist, args.sharded_circuit, args.sharded_samples)   # every rank takes part; rank 0 holds the record
+        sharded = sharded_legs(rank, world, local, dist, args.sharded_circuit, args.sharded_samples, args.sharded_reduced_noise)   # every rank takes part; rank 0 holds the record
         if rank == 0:
             result["sharded"] = sharded
     if rank == 0:
@@ -386,10 +387,10 @@ def run_batch(args, rank, world, local, dist):
     ctx.close()
     if world == 1 and not args.no_secure:
         sec = result["secure"] = secure_leg(B, local, max(3, args.steps // 2), args.oracle_sample)
-        # the deployable number beside the benchmark shape: the same batch at the 128-bit set for p = 15, norm2 70 (N = 1024 when
-        # the batch is wide enough for the k = 2 set).  `value` stays on BASELINE's P1024 configuration.
+        # the deployable number beside the benchmark shape: the same batch at the 128-bit set for p = 15, norm2 70 (N = 1024, k = 2).
+        # `value` stays on BASELINE's P1024 configuration.
         result["value_secure"] = dict(value=sec["value"], unit="FBS/s", decrypt_ok=sec["decrypt_ok"], bit_exact_vs_oracle=sec["bit_exact_vs_oracle"],
-                                      what="the same batch at the 128-bit parameter set choose_params(15, 70) returns for a batch of this width",
+                                      what="the same batch at the 128-bit parameter set choose_params(15, 70, glwe_dims=(1, 2)) returns: LutExecEnv.eval's default",
                                       params={k: sec["params"][k] for k in ("n", "N", "k", "l", "beta", "t", "gamma", "p", "key_bits_per_step",
                                                                             "security_bits_estimate")},
                                       margin_sigmas_at_norm2_70=sec["margin_sigmas_at_norm2_70"], kernel=sec["blind_rotate_kernel"])
@@ -406,7 +407,7 @@ def run_batch(args, rank, world, local, dist):
     return result
 
 
-def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p15", T=64):
+def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p15", T=64, reduced_noise=False):
     """--gpus N > 1: north_star's multi-GPU shape next to the weak-scaling headline, in the same line -- one whole mapped program
     (BASELINE configs[3] stand-in) on T samples, STRONG scaling, cut three ways by distributed.ShardedRunner: gate-sharded (every
     level's (gate, sample) batch over all ranks, one RCCL all-gather per level), sample-sharded (no data-path collective) and
@@ -414,13 +415,16 @@ def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p1
     import gzip
     import numpy as np
     import torch
-    from tfhe_fbs_map_amd import Context, Program, params_for, parse_fbs
+    from tfhe_fbs_map_amd import Context, Program, choose_params, params_for, parse_fbs
     from tfhe_fbs_map_amd.distributed import GpuBackend, ShardedRunner, choose_sharding
     with gzip.open(os.path.join(ROOT, "tests", "golden", circuit + ".json.gz"), "rb") as f:
         rec = json.loads(f.read().decode())
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
     low = env.lower()
-    prm = params_for(int(circuit.rsplit("_p", 1)[-1]))
+    # the 128-bit set LutExecEnv.eval would choose for this program (its own p and norm2; GLWE dimension 2 admitted): what a
+    # deployment's ranks run, every rank the same set.  --sharded-reduced-noise: the benchmark set instead.
+    p_msg = int(circuit.rsplit("_p", 1)[-1])
+    prm = params_for(p_msg) if reduced_noise else choose_params(p_msg, env.stats()["norm2_linprod"], glwe_dims=(1, 2))
     ctx = Context(prm, seed=1, device=local)
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
                    low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"])
@@ -428,7 +432,7 @@ def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p1
     clear = cleartext(low, bits)
     d_in = torch.from_numpy(ctx.encrypt(bits, nonce0=0).view(np.int64)).cuda()
     ctx.reserve(max_keyswitches=prog.max_width * T)
-    pick = choose_sharding(list(prog.level_width), T, world)
+    pick = choose_sharding(list(prog.level_width), T, world, params=prm)     # priced on the staircase of the set actually loaded
     legs = {}
     for label, gs in (("gate", 1), ("sample", world if T >= world else None), ("chosen", pick["sample_groups"])):
         if gs is None or (label == "chosen" and any(v["sample_groups"] == gs for v in legs.values())):
@@ -459,8 +463,10 @@ def sharded_legs(rank, world, local, dist, circuit="trivium_stream_v2__search_p1
     ctx.close()
     if rank != 0:
         return None
-    return dict(workload="%s (reference mapper output, %d bootstraps, depth %d, widest level %d) on %d samples, reduced-noise benchmark set, "
-                         "one evaluation per layout" % (circuit, prog.n_bootstrap, prog.depth, prog.max_width, T),
+    return dict(workload="%s (reference mapper output, %d bootstraps, depth %d, widest level %d) on %d samples, %s, "
+                         "one evaluation per layout" % (circuit, prog.n_bootstrap, prog.depth, prog.max_width, T,
+                                                        "reduced-noise benchmark set" if reduced_noise else "the 128-bit set chosen for its (p, norm2)"),
+                params=params_record(prm),
                 choose_sharding=dict(sample_groups=pick["sample_groups"], gate_groups=pick["gate_groups"],
                                      predicted_speedup_over_one_gpu=round(pick["predicted_speedup"], 2)), legs=legs)
 
@@ -504,19 +510,17 @@ def secure_leg(B, local, steps, oracle_sample=32):
         ctx.close()
         return rec
 
-    # a batch of a round or more is what the k = 2 sets are for (GLWE dimension 2 at N = 1024: `glwe_dims`, as ExecConfig asks for
-    # programs with wide levels); smaller batches and the sets beside it are k = 1
-    wide = B >= 768
-    rec = one(choose_params(15, 70, glwe_dims=(1, 2) if wide else (1,)))
+    # GLWE dimension 2 at N = 1024 admitted (`glwe_dims`), as ExecConfig does for every program; the k = 1 choice beside it
+    rec = one(choose_params(15, 70, glwe_dims=(1, 2)))
     if rec["params"]["k"] != 1:
-        rec["k1"] = dict(one(choose_params(15, 70)), note="the k = 1 choice for the same (p, norm2): N = 2048, what launches below a round run on")
+        rec["k1"] = dict(one(choose_params(15, 70)), note="the k = 1 choice for the same (p, norm2): N = 2048 (ExecConfig(glwe_dims=(1,)); shared rotations)")
     if rec["params"]["key_bits_per_step"] != 1:
         rec["one_key_bit_per_step"] = one(choose_params(15, 70, groups=(1,)))
     # the metric names N = 1024: at 128-bit noise that polynomial size carries small plaintext moduli only -- p = 4 is the
     # reference's own Trivium / Kreyvium comparison point (experiments/analyse_results.py:317)
     small = choose_params(4, 2)
     rec["n1024_p4"] = dict(one(small), note="128-bit set for p = 4 at norm2 = 2: the N = 1024 kernels at a secure parameter set")
-    if wide and choose_params(4, 2, glwe_dims=(1, 2)).k == 2:
+    if choose_params(4, 2, glwe_dims=(1, 2)).k == 2:
         rec["n1024_p4"]["k2"] = one(choose_params(4, 2, glwe_dims=(1, 2)))
     # BASELINE configs[4] (fbs_size = 31; no non-power-of-two N here: the 128-bit set is N = 2048 with two gadget levels)
     big = choose_params(31, 325)

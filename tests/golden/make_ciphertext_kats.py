@@ -42,9 +42,9 @@ SETS = {
     # give p = 15 at norm2 70 6.7 sigma by params.variances.  Frozen from the oracle (general in k) before the kernel existed.
     "secure_p15_k2_n1024_two_key_bits_per_step": dict(n=760, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=8, gamma_ksk=2, p_msg=15,
                                                       sigma_lwe=456472211, sigma_glwe=4, bsk_group=2),
-    # (round 4) the k = 2 set the selector SHIPS for (15, 70) -- n = 734, a 14-bit key switch -- in a batch long enough (2 x 256 CUs
-    # + 5) for the launcher to take the throughput shape k_blind_rotate_pairs_k2<10,4> (four bootstraps per workgroup); LAYOUTS
-    # below says which of its 517 ciphertexts are ordinary.  The n = 760 entry above stays: it is the freeze that predates the kernel.
+    # (round 4) the k = 2 set the selector SHIPS for (15, 70) -- n = 734, a 14-bit key switch -- in a batch long enough (3 x 256 CUs
+    # + 5) for the launcher to take the throughput shape k_blind_rotate_pairs_k2<10,4> (four bootstraps per workgroup; up to three
+    # bootstraps per CU it prefers the twelve-waves-per-bootstrap shape); LAYOUTS below says which of its 773 ciphertexts are ordinary.  The n = 760 entry above stays: it is the freeze that predates the kernel.
     "secure_p15_k2_shipped_n734_four_per_workgroup": dict(n=734, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=7, gamma_ksk=2, p_msg=15,
                                                           sigma_lwe=737229119, sigma_glwe=4, bsk_group=2),
     "secure_p4_n1024": dict(n=638, log_n_poly=10, k=1, l_bsk=2, beta_bsk=8, t_ksk=12, gamma_ksk=1, p_msg=4, sigma_lwe=4328098537,
@@ -57,7 +57,7 @@ COUNT = 5
 # name -> (batch size, positions of the ORDINARY ciphertexts): every other ciphertext of the batch is trivial (mask zero, so every
 # blind-rotation step is skipped: milliseconds in the oracle, and on the GPU a bootstrap that only keeps its workgroup's barriers
 # company).  The ordinary ones sit in all four sub-slots of the first workgroup, in a middle one, and in the ragged last one.
-LAYOUTS = {"secure_p15_k2_shipped_n734_four_per_workgroup": (517, [0, 1, 2, 3, 258, 513, 515, 516])}
+LAYOUTS = {"secure_p15_k2_shipped_n734_four_per_workgroup": (773, [0, 1, 2, 3, 386, 769, 771, 772])}
 
 
 def digest(a):

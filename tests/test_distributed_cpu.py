@@ -10,7 +10,7 @@ import pytest
 
 from tests.helpers import load_fixture, subsample
 from tfhe_fbs_map_amd import parse_fbs
-from tfhe_fbs_map_amd.distributed import choose_sharding, launch_ms, plan_levels, split_range
+from tfhe_fbs_map_amd.distributed import choose_sharding, launch_family, launch_ms, plan_levels, split_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -108,3 +108,28 @@ def test_choose_sharding_prefers_samples_and_falls_back_to_gates():
     assert {(k["sample_groups"], k["gate_groups"]) for k in choose_sharding(widths, 64, 8)["candidates"]} == {(1, 8), (2, 4), (4, 2), (8, 1)}
     # the staircase: one more bootstrap than a CU-round costs a second round; whole rounds of 1024 add up
     assert launch_ms(257) > 1.7 * launch_ms(256) and launch_ms(4096) < 4.2 * launch_ms(1024)
+
+
+def test_layouts_are_priced_on_the_staircase_of_the_set_actually_loaded():
+    """`choose_sharding(..., params=)`: every parameter set follows the launch-time staircase of the kernels IT runs on
+    (schedule.LAUNCH_FAMILIES), scaled by its blind-rotation steps -- not the benchmark shape's times a scalar."""
+    from tfhe_fbs_map_amd import P1024
+    from tfhe_fbs_map_amd.params import choose_params
+    k2, n2048, p31 = choose_params(15, 70, glwe_dims=(1, 2)), choose_params(15, 70), choose_params(31, 325)
+    assert launch_family(k2) == ("k2", 1.0) and launch_family(n2048)[0] == "n2048" and launch_family(p31)[0] == "n2048_l2"
+    assert launch_family(P1024) == ("p1024", 1.0)
+    assert launch_family(choose_params(4, 2, glwe_dims=(1, 2))) == ("k2", (630 // 2) / 367)      # fewer steps, the same kernels
+    name, scale = launch_family(choose_params(4, 2))                                             # no staircase of its own: P1024's
+    assert name == "p1024" and 0.5 < scale < 1.0
+    # the k = 2 family: one bootstrap per CU costs one round of the twelve-wave shape, 257 two, 769 a round of four per workgroup
+    assert launch_ms(256, params=k2) < 2.5 < 4.0 < launch_ms(257, params=k2) < 4.6 and launch_ms(769, params=k2) < 7.0
+    assert launch_ms(2048, params=k2) < 2.05 * launch_ms(1024, params=k2)
+    assert launch_ms(1124, params=k2) < launch_ms(1024, params=k2) + launch_ms(100, params=k2) + 1e-9
+    assert launch_ms(256, params=k2) < launch_ms(256, params=n2048) < launch_ms(256, params=p31)
+    # an adder's levels (widths 1-3) at the harness's T = 1000 over 8 ranks: priced per set, and the ciphertexts of a k = 2 set are 2 N + 1 words
+    widths = [1, 2, 3, 2] * 8
+    a, b = choose_sharding(widths, 1000, 8, params=k2), choose_sharding(widths, 1000, 8, params=p31)
+    assert a["predicted_ms"] < b["predicted_ms"] and a["single_gpu_ms"] < b["single_gpu_ms"]
+    assert 5.0 < a["predicted_speedup"] <= 8.0
+    gate = [c for c in choose_sharding([300, 400], 4, 8, params=k2)["candidates"] if c["gate_groups"] == 8][0]
+    assert gate["allgather_ms"] > 0

@@ -92,3 +92,4 @@ def test_two_rank_line_carries_the_sharded_legs():
     assert legs["gate"]["gate_groups"] == 2 and legs["gate"]["collectives_per_step"] > 0 and legs["gate"]["allgather_ms_rank0"] >= 0
     assert legs["sample"]["collectives_per_step"] == 0 and legs["sample"]["allgather_ms_rank0"] == 0
     assert d["sharded"]["choose_sharding"]["sample_groups"] * d["sharded"]["choose_sharding"]["gate_groups"] == 2
+    assert d["sharded"]["params"]["security_bits_estimate"] >= 127.9           # the legs run the 128-bit set chosen for the circuit

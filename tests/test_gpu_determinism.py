@@ -17,5 +17,5 @@ def test_whole_cu_kernels_are_deterministic():
     lines = [ln for ln in r.stdout.splitlines() if "runs identical" in ln]
     assert len(lines) >= 20 and all("identical: True" in ln and "decrypts: True" in ln for ln in lines), r.stdout
     for kernel in ("k_blind_rotate_cu_pairs<11,1>", "k_blind_rotate_cu_pairs<11,2>", "k_blind_rotate_cu<10,3,2>", "k_blind_rotate_cu<10,3,2,lean>",
-                   "k_blind_rotate_pairs_k2<10,4>"):
+                   "k_blind_rotate_pairs_k2<10,4>", "k_blind_rotate_cu_k2"):
         assert any(kernel in ln for ln in lines), kernel

@@ -56,9 +56,12 @@ def recipe(name):
     if name == "k_blind_rotate_cu_pairs<11,2>":           # ... with two gadget levels: every launch, round after round
         return dict(log_n=11, l=2, beta=10, group=2, count=CUS + 21, knobs={})
     m = re.fullmatch(r"k_blind_rotate_pairs_k2<10,(\d)>", name)
-    if m:                                                 # GLWE dimension k = 2: one, two or four bootstraps per workgroup, a ragged last one
-        fpw = int(m.group(1))
-        return dict(log_n=10, l=1, beta=20, group=2, k=2, count={1: 41, 2: CUS + 41, 4: 2 * CUS + 41}[fpw], knobs={})
+    if m:                                                 # GLWE dimension k = 2 on three waves per bootstrap: one, two or four bootstraps per
+        fpw = int(m.group(1))                             # workgroup, a ragged last one (up to three per CU the launcher prefers the shape below)
+        return dict(log_n=10, l=1, beta=20, group=2, k=2, count={1: 41, 2: CUS + 41, 4: 3 * CUS + 41}[fpw],
+                    knobs={} if fpw == 4 else dict(br_k2_shape=3))
+    if name == "k_blind_rotate_cu_k2":                    # ... one bootstrap on the twelve waves of a workgroup: two rounds, the second partial
+        return dict(log_n=10, l=1, beta=20, group=2, k=2, count=CUS + 41, knobs={})
     m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))

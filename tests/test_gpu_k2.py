@@ -27,14 +27,18 @@ def toy(**kw):
 
 
 @pytest.mark.parametrize("beta", [21, 17, 12])
-def test_ragged_batches_bit_exact(nat, beta):
+@pytest.mark.parametrize("shape", [0, 3])
+def test_ragged_batches_bit_exact(nat, beta, shape):
     """Batches that are not multiples of the four bootstraps of a workgroup, all three table modes and a multi-valued table, a
     trivial ciphertext (every step skipped: the other three bootstraps of its workgroup still meet their barriers) and maximal
-    residues: every output word equal to the oracle's."""
+    residues: every output word equal to the oracle's -- by the launcher's own choice (shape 0: one bootstrap on the twelve waves
+    of a workgroup up to three per CU, four-bootstrap workgroups beyond) and with the three-waves-per-bootstrap kernels forced
+    at every size (shape 3: one, two, four bootstraps per workgroup)."""
     prm = toy(beta_bsk=beta)
     ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
+    ctx.tune(br_k2_shape=shape)
     tv = ctx.tvset(TABLES)
-    for B in (1, 2, 3, 4, 5, 7, 21, 64, 301, 600):
+    for B in (1, 2, 3, 4, 5, 7, 21, 64, 301, 600, 900):
         msgs = np.arange(B) % 7
         ids = (np.arange(B) % 4).astype(np.uint32)
         msgs[ids == 1] = np.arange(B)[ids == 1] % 14
@@ -46,7 +50,10 @@ def test_ragged_batches_bit_exact(nat, beta):
         ctx.profile(True)
         ctx.profile_read(reset=True)
         got = ctx.bootstrap_batch(tv, cts, ids)
-        want = "k_blind_rotate_pairs_k2<10,%d>" % (1 if B <= 256 else 2 if B <= 512 else 4)
+        if shape == 3:
+            want = "k_blind_rotate_pairs_k2<10,%d>" % (1 if B <= 256 else 2 if B <= 512 else 4)
+        else:
+            want = "k_blind_rotate_cu_k2" if B <= 768 else "k_blind_rotate_pairs_k2<10,4>"
         assert want in ctx.profile_kernels(), (want, ctx.profile_kernels())
         ref, _ = o.bootstrap_batch(cts, TABLES, ids)
         assert np.array_equal(got, ref), B
@@ -84,8 +91,9 @@ def test_shipped_k2_sets_at_full_size_against_the_oracle(nat, p, norm2):
     k_blind_rotate_pairs_k2<10,4> -- word for word against the oracle on ciphertexts that sit in every sub-slot (bootstrap
     0 .. 3 of a workgroup = three waves on other SIMDs each) of the first, a middle and the last workgroup, trivial
     ciphertexts (every step skipped: the bootstrap only keeps its workgroup's barriers company) beside ordinary ones.  Then a
-    launch of 1 024 + 100: whatever the launcher makes of it (one launch of ragged four-bootstrap workgroups today; a cut into
-    a round and a small launch would show as two kernels), checked at both ends and either side of bootstrap 1 024."""
+    launch of 1 024 + 100, which the launcher CUTS -- a whole round, and the leftovers on the twelve-waves-per-bootstrap shape
+    k_blind_rotate_cu_k2 -- checked at both ends and either side of the cut; then 300: two rounds of that shape alone, the
+    second partial, checked at the ends of both."""
     import torch
     from tfhe_fbs_map_amd.params import choose_params, margin_sigmas, security_bits
     prm = choose_params(p, norm2, glwe_dims=(1, 2))
@@ -95,12 +103,14 @@ def test_shipped_k2_sets_at_full_size_against_the_oracle(nat, p, norm2):
     rng = np.random.default_rng(7 + p)
     tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(16)]
     tv = ctx.tvset(tables)
-    for B, pick in ((1024, [0, 1, 2, 3, 4, 5, 6, 7, 508, 509, 510, 511, 1020, 1021, 1022, 1023, 301, 778]),
-                    (1124, [0, 3, 1021, 1023, 1024, 1025, 1026, 1027, 1100, 1120, 1121, 1122, 1123])):
+    for B, pick, want in ((1024, [0, 1, 2, 3, 4, 5, 6, 7, 508, 509, 510, 511, 1020, 1021, 1022, 1023, 301, 778], ["k_blind_rotate_pairs_k2<10,4>"]),
+                          (1124, [0, 3, 1021, 1023, 1024, 1025, 1026, 1027, 1100, 1120, 1121, 1122, 1123],
+                           ["k_blind_rotate_cu_k2", "k_blind_rotate_pairs_k2<10,4>"]),
+                          (300, [0, 1, 2, 254, 255, 256, 257, 298, 299], ["k_blind_rotate_cu_k2"])):
         msgs = rng.integers(0, p, B)
         ids = (np.arange(B) % 16).astype(np.uint32)
         cts = ctx.encrypt(msgs, nonce0=100)
-        trivial = [1, 6, 509, 1022, B - 1]
+        trivial = [i for i in (1, 6, 509, 1022, B - 1) if i < B]
         for i in trivial:
             cts[i, :-1] = 0                                          # mask zero: every modulus-switched mask word is zero
         d_in = torch.from_numpy(cts.view(np.int64)).cuda()
@@ -112,7 +122,7 @@ def test_shipped_k2_sets_at_full_size_against_the_oracle(nat, p, norm2):
         ctx.sync()
         launched = [k for k in ctx.profile_kernels() if "blind_rotate" in k]
         ctx.profile(False)
-        assert "k_blind_rotate_pairs_k2<10,4>" in launched and all("_k2<" in k for k in launched), launched
+        assert sorted(launched) == want, launched
         got = d_out.cpu().numpy().view(np.uint64)
         ref, _ = o.bootstrap_batch(cts[pick], tables, ids[pick])
         assert np.array_equal(got[pick], ref), (B, launched)
@@ -158,17 +168,23 @@ def test_unsupported_k2_shapes_are_refused(nat):
             nat.Context(toy(**kw), seed=1)
 
 
-def test_eval_takes_k2_for_wide_levels_only():
-    """`LutExecEnv.eval`: a program whose levels average a round of bootstraps or more runs on the k = 2 set (and decrypts to the
-    reference's goldens); the same program on a few samples stays on the k = 1 set with its one-bootstrap-per-CU kernels."""
+def test_eval_takes_k2_at_every_width():
+    """`LutExecEnv.eval` by default: the k = 2 set whether the program's levels are launches of a round of bootstraps (T = 200: the
+    four-per-workgroup shape) or of a handful (T = 8: one bootstrap on the twelve waves of a workgroup) -- both decrypt to the
+    reference's goldens; `glwe_dims=(1,)` keeps a program on the k = 1 set."""
     from tfhe_fbs_map_amd import ExecConfig, parse_fbs
     rec = load_fixture("mul16__search_p15")
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
-    for T, want_k in ((200, 2), (8, 1)):
+    for T, kernel in ((200, "k_blind_rotate_pairs_k2<10,4>"), (8, "k_blind_rotate_cu_k2")):
         cfg = ExecConfig(seed=9)
         ins, expect = subsample(rec, T)
+        ctx, _ = cfg.choose(env, 15, samples=T)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
         got = env.eval(ins, config=cfg)
-        assert cfg.last_choice["params"].k == want_k, (T, cfg.last_choice["params"])
+        assert cfg.last_choice["params"].k == 2 and cfg.last_choice["samples"] == T, (T, cfg.last_choice)
+        assert kernel in ctx.profile_kernels(), (T, sorted(ctx.profile_kernels()))
+        ctx.profile(False)
         for name, v in expect.items():
             assert (int(got[name]) == int(v)) if isinstance(v, int) else np.array_equal(np.asarray(got[name]).reshape(-1), v), name
     cfg = ExecConfig(seed=9, glwe_dims=(1,))

@@ -131,7 +131,8 @@ def test_exec_estimate_is_the_references_total_cost_in_this_executors_unit():
 
 def test_glwe_dimension_two_is_an_option_not_the_default():
     """k = 2 (N = 1024, two key bits per step, one level: what k_blind_rotate_pairs_k2 is built for) is returned only when asked
-    for, where it is cheaper and reaches the margin; ExecConfig asks for it by the program's bootstraps per level x samples."""
+    for, where it is cheaper and reaches the margin; ExecConfig asks for it for every program (since the twelve-wave latency
+    shape it is ahead at every launch size), unless told to stay on k = 1."""
     from tfhe_fbs_map_amd import ExecConfig
     from tfhe_fbs_map_amd.params import bootstrap_cost, choose_params, margin_sigmas, security_bits
     a, b = choose_params(15, 70), choose_params(15, 70, glwe_dims=(1, 2))
@@ -140,5 +141,5 @@ def test_glwe_dimension_two_is_an_option_not_the_default():
     assert choose_params(31, 325, glwe_dims=(1, 2)).k == 1          # p = 31 does not fit 2N = 2048 slots at 6 sigma
     assert choose_params(15, 70, glwe_dims=(1, 2), groups=(1,)).k == 1
     cfg = ExecConfig(seed=1)
-    assert cfg.params_choice(15, 70).k == 1 and cfg.params_choice(15, 70, wide=True).k == 2
-    assert ExecConfig(seed=1, glwe_dims=(1,)).params_choice(15, 70, wide=True).k == 1
+    assert cfg.params_choice(15, 70).k == 2 and cfg.params_choice(15, 70, glwe_dims=(1,)).k == 1
+    assert ExecConfig(seed=1, glwe_dims=(1,)).params_choice(15, 70).k == 1

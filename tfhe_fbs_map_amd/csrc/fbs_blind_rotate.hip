@@ -567,7 +567,7 @@ static int upload_keys_t(fbs_ctx *ctx) {
         constexpr int LLS = lanes_log2_for_small_launch(LOGN);
         if constexpr (LLS != LL) {
             // (two key bits per step: a second copy of the 1.5 times larger key only where a kernel reads it -- N = 2048, l <= 2)
-            // (... and N = 1024 at GLWE dimension 2: the whole-workgroup latency shapes of fbs_blind_rotate_k2.hip)
+            // (... and N = 1024 at GLWE dimension 2: the whole-workgroup latency shape of fbs_blind_rotate_k2.hip)
             if (ctx->group == 1 || (LOGN == 11 && ctx->p.l_bsk <= 2) || (LOGN == 10 && ctx->p.k == 2)) {
                 if (e == hipSuccess && !ctx->d_bsk_hat_small) e = hipMalloc(&ctx->d_bsk_hat_small, polys * N * 8);
                 if (e == hipSuccess) {
@@ -576,16 +576,6 @@ static int upload_keys_t(fbs_ctx *ctx) {
                                        n_inv, polys);
                     e = hipGetLastError();
                 }
-            }
-        }
-    }
-    if constexpr (LOGN == 10) {
-        if (e == hipSuccess && ctx->p.k == 2 && ctx->tune.br_k2_mid_copy) {   // (a third copy, for the six-wave shape: experiments)
-            if (!ctx->d_bsk_hat_mid) e = hipMalloc(&ctx->d_bsk_hat_mid, polys * N * 8);
-            if (e == hipSuccess) {
-                launch_bsk_transform_two_waves(d_src, reinterpret_cast<double *>(ctx->d_bsk_hat_mid), reinterpret_cast<const double *>(ctx->d_tw_fwd),
-                                               fq_centered(fq_inv(N)), polys, ctx->stream);
-                e = hipGetLastError();
             }
         }
     }
@@ -704,6 +694,15 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     if (p.k == 2) {   // GLWE dimension 2 (N = 1024, two key bits per step, one level: dev_supported admits nothing else)
         if (gv.acc_rows || gv.row_words) return set_error(ctx, FBS_E_INVALID, "shared rotations are built for k = 1");
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
+        // a launch longer than a round of four-bootstrap workgroups whose last round would be (far) from full: whole rounds first,
+        // the rest as a launch of its own in the twelve-wave shape (1 124 = 1 024 + 100: 7.3 + 2.1 ms against two rounds' 14.5)
+        const size_t per_round = 4 * (size_t)ctx->cu_count, rest_n = count % per_round;
+        const bool cut = count > per_round && rest_n != 0 && rest_n <= K2_CU_ROUNDS * (size_t)ctx->cu_count && ctx->tune.br_whole_cu &&
+                         ctx->tune.br_k2_shape == 0 && ctx->tune.br_cu_kernel && ctx->tune.br_cu_max_per_cu >= 1;
+        if (cut) {
+            a.count = count - rest_n;
+            a.gv.count = a.count;
+        }
         hipEvent_t c0, c1;
         prof_begin(ctx, 1, stream, &c0, &c1);
         if (!launch_blind_rotate_k2(ctx, a, stream, &ctx->prof.kernel[1])) {
@@ -712,7 +711,12 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
         }
         prof_end(ctx, 1, stream, c0, c1);
         FBS_HIP(ctx, hipGetLastError());
-        return FBS_OK;
+        if (!cut) return FBS_OK;
+        GateView rest = gv;
+        rest.f_begin += count - rest_n;
+        rest.count = rest_n;
+        if (rest.out_rows) rest.out_rows += (count - rest_n) * (size_t)(rest.row_words ? rest.row_words : ctx->D + 1);
+        return dev_blind_rotate(ctx, tv, rest, d_ms, stream);
     }
     if (ctx->group == 2) {
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);

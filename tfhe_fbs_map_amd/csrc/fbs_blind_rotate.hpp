@@ -77,11 +77,11 @@ bool launch_blind_rotate_cu(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
 // ... with two key bits per step (N = 2048, one gadget level)
 bool launch_blind_rotate_cu_pairs(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_cu_catalog(std::vector<std::string> *out);
-// fbs_blind_rotate_k2.hip: GLWE dimension k = 2 at N = 1024 (two key bits per step, one gadget level): three waves per bootstrap,
-// four bootstraps per workgroup.  Returns false when the context is not of that shape.
+// fbs_blind_rotate_k2.hip: GLWE dimension k = 2 at N = 1024 (two key bits per step, one gadget level): three waves per bootstrap and
+// one / two / four bootstraps per workgroup, or one bootstrap on the twelve waves of a workgroup (launches that leave most of the
+// chip empty).  Returns false when the context is not of that shape.
+constexpr size_t K2_CU_ROUNDS = 3;   // bootstraps per CU up to which a k = 2 launch takes the twelve-wave shape, round after round
 bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_k2_catalog(std::vector<std::string> *out);
-// ... and the key transform into the evaluation order of its six-wave latency shape (WavesNtt<10, 1>)
-void launch_bsk_transform_two_waves(const uint64_t *d_src, double *d_dst, const double *tw_fwd, double n_inv, size_t polys, hipStream_t stream);
 
 }  // namespace fbs

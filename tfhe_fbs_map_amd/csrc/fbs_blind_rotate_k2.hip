@@ -195,38 +195,51 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The LATENCY shape: ONE k = 2 bootstrap on a whole workgroup of twelve (LOGW = 2) or six (LOGW = 1) waves -- what a launch that
-// leaves most of the chip empty wants (a rank's slice of a level of a sharded circuit, a narrow level): a bootstrap is n / 2
-// dependent steps, and in the three-waves-per-bootstrap kernel above each step is one wave's 2 965 instructions whatever the
-// chip has idle (3.4-3.6 ms per launch at n = 734-760).  Here each of the three GLWE components is dealt over 2^LOGW waves as in
-// k_blind_rotate_cu_pairs (fbs_blind_rotate_cu.hip; WavesNtt<10, LOGW>): LOGW cross stages in registers, ONE trip through LDS to
-// re-deal, then wave-private part transforms (LaneNtt256 at 4 coefficients per lane / LaneNtt512 at 8: register <-> lane
-// transpositions, one LDS exchange each).  Per step, component c = waves c 2^LOGW ..:
+// The LATENCY shape: ONE k = 2 bootstrap on the twelve waves of a workgroup -- what a launch that leaves most of the chip empty
+// wants (a rank's slice of a level of a sharded circuit, a narrow level, the leftovers of a round): a bootstrap is n / 2 dependent
+// steps, and in the three-waves-per-bootstrap kernel above each step is one wave's 2 965 instructions whatever the chip has idle
+// (3.3-3.5 ms per launch at n = 734).  Here each of the three GLWE components is dealt over FOUR waves as in the k = 1 whole-CU
+// kernels (fbs_blind_rotate_cu.hip; WavesNtt<10, 2>): two cross stages in registers, ONE trip through LDS to re-deal, then
+// wave-private 256-point transforms at 4 coefficients per lane (LaneNtt256: register <-> lane transpositions, one LDS exchange
+// each).  Per step, component c = waves 4 c .. 4 c + 3:
 //   ACC_c itself -> balanced digit -> cross stages -> re-deal (barrier 1) -> private forward transform
-//   -> bundle of row c (three samples x three columns: nine key polynomials' words, fetched register pair by register pair)
-//      times the digits: products for all three output components; the own one stays in registers, the other two are HANDED
-//      to the waves that hold the same evaluation points of those components -- plain stores into the receiver's two slots
-//      (barrier 2), no atomics: a wave has exactly two senders
+//   -> bundle of row c (three samples x three columns: nine key polynomials' words) times the digits: products for all three
+//      output components; the own one stays in registers, the other two are HANDED to the waves that hold the same evaluation
+//      points of those components -- plain stores into the receiver's two slots (barrier 2); no atomics: a wave has exactly
+//      two senders
 //   -> sum, private inverse transform, re-deal back (barrier 3), joining stages, accumulate.
-// Three workgroup barriers per step, as the k = 1 shape.  Evaluation points: array position P = M w + j of a part holds the value
-// at psi^(2 bitrev10(P) + 1), and after the part's forward transform the register index is the LOW bits of j, i.e. the HIGH bits
-// of the bit reversal: 2 bitrev(P) + 1 = o_lane + (2N / E) k_m with psi^(2N/E) a primitive E-th root of unity (E = 4: i; E = 8: an
-// eighth root) -- ONE table look-up per lane and exponent, then a wave-uniform choice among its products with that root's powers.
+// Three workgroup barriers per step, as the k = 1 shape; 783 vector instructions per wave and step, 166 registers, nothing spilled.
+// THE KEY ROWS OF A STEP DO NOT DEPEND ON ITS DATA.  One workgroup per CU pulls a step's whole row out of L2 by itself (27
+// polynomials, 221 KB; a CU streams ~100 GB/s from L2: 2.2 us of a 6 us step), so when the words are asked for decides how much of
+// that is waited for.  Measured at n = 734, per launch of 64 / 256 bootstraps (tools/k2_latency.py, one box):
+//     first register pair at the top of the step, second after the first's products      2.30 / 2.51 ms
+//     both at the top                                                                      2.49 / 2.66
+//     first at the top, second after the re-deal barrier                                   2.43 / 2.62
+//     first at the top, second ahead of the forward transform's last four stages           2.20 / 2.39
+//     FIRST DURING THE STEP BEFORE (after its hand-over barrier: the words stream in behind the inverse transform),
+//       second ahead of the forward transform's last four stages                           1.96 / 2.21   <- this kernel
+//     ... second at the top of the step / one step ahead as well (after the re-deal back)  2.26 / 2.48,  2.17 / 2.38
+// (more loads in flight than one register pair's is worse every time).  Two rounds of it serve 512 bootstraps in 4.2 ms (the
+// three-waves-per-bootstrap kernel: 4.85).  The same shape on SIX waves (two per component, 512-point parts at 8 coefficients per
+// lane, 223 registers, 89 KB of LDS: one workgroup per CU all the same) was built and measured: 2.91 ms at 64 and at 256 -- dropped.
+// Evaluation points: array position P = 256 w + j of part w holds the value at psi^(2 bitrev10(P) + 1), and after the part's
+// forward transform register m = (j1 j0) of lane ln holds j = (ln & 15) << 4 | (ln >> 4) << 2 | m: the register index is the two
+// LOWEST bits of P, the two HIGHEST of its bit reversal, so 2 bitrev(P) + 1 = o_lane + 512 k_m with k_m = j1 + 2 j0, and
+// psi^512 = R is a primitive FOURTH root of unity: zeta_m^e = psi^(e o_lane) R^(e k_m).  ONE table look-up per lane and exponent;
+// R^e is wave-uniform (picked among 1, R, -1, -R by scalar instructions) and multiplied in once.
 // LDS (doubles): [3][N] re-deal + private forward exchange; [3][2][N] hand-over slots -- slot 0 doubles as the private inverse
-// exchange and the re-deal back (wave w receives in the words it alone touches until the re-deal, as in k_blind_rotate_cu_pairs);
-// the inverse per-lane twiddles of 512-point parts: 72 KB (LOGW = 2), 89 KB (LOGW = 1).
-template <int LOGW>
-__global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
-    constexpr int LOGN = 10, K1 = 3, PARTS = 1 << LOGW;
-    using W = WavesNtt<LOGN, LOGW>;
+// exchange and the re-deal back (wave w receives in the words it alone touches until the re-deal, as in k_blind_rotate_cu_pairs):
+// 72 KB.
+__global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
+    constexpr int LOGN = 10, K1 = 3, PARTS = 4;
+    using W = WavesNtt<LOGN, 2>;
     using Part = typename W::Half;
-    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M, EP = W::EP, LOGE = W::LOGE;
-    static_assert((LOGW == 2 && std::is_same<Part, LaneNtt256>::value && E == 4) || (LOGW == 1 && std::is_same<Part, LaneNtt512>::value && E == 8),
-                  "four waves per polynomial at 4 coefficients per lane, or two at 8");
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, M = W::M;
+    static_assert(std::is_same<Part, LaneNtt256>::value && E == 4 && W::EP == 1, "four waves per polynomial at 4 coefficients per lane");
     using Tw = CuTwiddles<Part, false, PARTS>;
-    __shared__ double lds_all[K1 * N + K1 * 2 * N + Tw::LDS_WORDS];
+    __shared__ double lds_all[K1 * N + K1 * 2 * N];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t comp = wave >> LOGW, w = wave & (PARTS - 1u);            // GLWE component, part of it (both wave-uniform)
+    const uint32_t comp = wave >> 2, w = wave & 3u;                          // GLWE component, part of it (both wave-uniform)
     const uint32_t t = threadIdx.x & (LANES - 1), ln = t & 63u;             // thread of the component, lane
     double *xf = lds_all + comp * N;                                        // re-deal region of this component
     double *hand = lds_all + K1 * N;                                        // [component][slot][N]
@@ -236,11 +249,11 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
     // where this wave's products for the two other components go: the same part of their slots.  Component c receives from
     // c + 2 in slot 0 and from c + 1 in slot 1 (mod 3).  c1 = comp + 1, c2 = comp + 2 (mod 3)
     const uint32_t c1 = comp == 2u ? 0u : comp + 1u, c2 = comp == 0u ? 2u : comp - 1u;
-    double *to_c1 = hand + (c1 * 2u + 0u) * N + w * M;                      // c1 = comp + 1 receives from comp = c1 + 2: slot 0
-    double *to_c2 = hand + (c2 * 2u + 1u) * N + w * M;                      // c2 = comp + 2 receives from comp = c2 + 1: slot 1
+    double *to_c1 = hand + (c1 * 2u + 0u) * N + w * M;
+    double *to_c2 = hand + (c2 * 2u + 1u) * N + w * M;
     const uniform_doubles big_f = (uniform_doubles)(uintptr_t)a.tw_fwd, big_i = (uniform_doubles)(uintptr_t)a.tw_inv;
     Tw tw;
-    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, lds_all + 3 * K1 * N);
+    tw.init(big_f, big_i, a.tw_fwd + W::LANE_TABLE_OFFSET, a.tw_inv + W::LANE_TABLE_OFFSET, w, ln, nullptr);
 
     const bool live = (size_t)blockIdx.x < a.count;
     const size_t f = live ? (size_t)blockIdx.x : a.count - 1;
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
     const uint32_t *ms = a.ms + ms_row * (a.n + 1);
     const uint64_t *tv = a.tvs + (size_t)table * N;
 
-    double acc[E];   // ACC = (0, 0, X^{-b~} * TV), centred; register m of thread t = coefficient t + LANES m
+    double acc[E];   // ACC = (0, 0, X^{-b~} * TV), centred; register m of thread t = coefficient t + 256 m
     {
         const uint32_t r = (2u * N - ms[a.n]) & (2u * N - 1u);
 #pragma unroll
@@ -265,20 +278,30 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
     const double round_scale = fp_exp2i(-(int)(FQ_BITS - a.beta));
     const uint32_t bhalf = 1u << (a.beta - 1);
     const double round_offset = 0.5 + fp_exp2i((int)a.beta) + (double)bhalf;
-    // cross-stage twiddles: nodes 1 .. PARTS - 1 of the big tree (wave-uniform)
-    double cw[PARTS - 1], iw[PARTS - 1];
-#pragma unroll
-    for (int i = 0; i < PARTS - 1; i++) cw[i] = big_f[1 + i], iw[i] = big_i[1 + i];
-    // o_lane = 2 bitrev10(M w + the lane's part of j) + 1; the register part of j is its low log2(E) bits
-    const uint32_t j_lane = LOGW == 2 ? (((ln & 15u) << 4) | ((ln >> 4) << 2)) : (((ln & 31u) << 4) | ((ln >> 5) << 3));
-    const uint32_t o_lane = 2u * (__builtin_bitreverse32((uint32_t)M * w + j_lane) >> (32 - LOGN)) + 1u;
-    const uniform_doubles psi_u = (uniform_doubles)(uintptr_t)a.psi_pow;
-    constexpr uint32_t ROOT = 2u * N / E;                                   // psi^ROOT: a primitive E-th root of unity
-    const double om1 = psi_u[ROOT], om2 = E == 8 ? psi_u[2 * ROOT] : 0.0, om3 = E == 8 ? psi_u[3 * ROOT] : 0.0;
-    __syncthreads();   // (the inverse twiddle table of 512-point parts is in place)
+    // cross-stage twiddles: nodes 1, 2, 3 of the big tree (wave-uniform, scalar registers for the whole rotation)
+    const double cw[3] = {big_f[1], big_f[2], big_f[3]}, iw[3] = {big_i[1], big_i[2], big_i[3]};
+    const uint32_t o_lane = 2u * (__builtin_bitreverse32((uint32_t)M * w + (((ln & 15u) << 4) | ((ln >> 4) << 2))) >> (32 - LOGN)) + 1u;
+    const double root = ((uniform_doubles)(uintptr_t)a.psi_pow)[N / 2];     // R = psi^512
 
+    // row `comp` of the three samples of a step: [sample][row][column][N]; column c' = the products for component c'.  The
+    // columns are taken in ROTATED order -- d = 0, 1, 2 stands for component comp + d (mod 3): own, next, next but one -- which
+    // costs nothing (the column is the load's scalar offset) and makes "which product goes where" the same code in every wave
     const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
+    const uint32_t col_bytes[K1] = {comp * (uint32_t)(N * 8), c1 * (uint32_t)(N * 8), c2 * (uint32_t)(N * 8)};
+    auto request = [&](uint32_t step, auto jc, double2 (&k)[3][K1]) {
+        constexpr int j = decltype(jc)::value;
+        const KeyRows keys(a.bsk_hat + ((size_t)step * 3 * K1 + comp) * K1 * N);
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+            for (int d = 0; d < K1; d++)
+                k[jj][d] = keys.load(t16 + (uint32_t)(j * LANES * 16), (uint32_t)(jj * K1 * K1) * (uint32_t)(N * 8) + col_bytes[d]);
+    };
+    using Pair0 = std::integral_constant<int, 0>;
+    using Pair1 = std::integral_constant<int, 1>;
     const uint32_t n_pairs = a.n / 2;
+    double2 kw0[3][K1], kw1[3][K1];
+    request(0, Pair0{}, kw0);
     uint32_t e0_next = ms[0], e1_next = ms[1];
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
@@ -286,89 +309,60 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
         e[1] = __builtin_amdgcn_readfirstlane(e1_next);
         e0_next = ms[2 * i + 2 < a.n ? 2 * i + 2 : a.n];   // (the last pair re-reads the body word and ignores it)
         e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
-        if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the workgroup: one bootstrap)
+        const uint32_t i_next = i + 1 < n_pairs ? i + 1 : i;   // (the last step asks for its own row again: in bounds, unused)
+        if (e[0] == 0 && e[1] == 0) {                       // the bundle is zero (uniform over the workgroup: one bootstrap)
+            request(i_next, Pair0{}, kw0);
+            continue;
+        }
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
 
-        // ---- what memory has to bring: psi^(e o_lane) for the three exponents, and the first register pair's key words --------
+        // ---- psi^(e o_lane) for the three exponents: one look-up each (psi^(x + N) = -psi^x) -------------------------------------
         double A[3];
 #pragma unroll
         for (int jj = 0; jj < 3; jj++) {
             const uint32_t x = __umul24(e[jj], o_lane) & (2u * N - 1u);
             const double v = a.psi_pow[x & (N - 1)];
-            A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));   // psi^(x + N) = -psi^x
+            A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));
         }
-        // row `comp` of the three samples of step i: [sample][row][column][N]; column c' = the products for component c'.  The
-        // columns are taken in ROTATED order -- d = 0, 1, 2 stands for component comp + d (mod 3): own, next, next but one -- which
-        // costs nothing (the column is the load's scalar offset) and makes "which product goes where" the same code in every wave
-        const KeyRows keys(a.bsk_hat + ((size_t)i * 3 * K1 + comp) * K1 * N);
-        const uint32_t col_bytes[K1] = {comp * (uint32_t)(N * 8), c1 * (uint32_t)(N * 8), c2 * (uint32_t)(N * 8)};
-        auto request = [&](auto jc, double2 (&k)[3][K1]) {
-            constexpr int j = decltype(jc)::value;
-#pragma unroll
-            for (int jj = 0; jj < 3; jj++)
-#pragma unroll
-                for (int d = 0; d < K1; d++)
-                    k[jj][d] = keys.load(t16 + (uint32_t)(j * LANES * 16), (uint32_t)(jj * K1 * K1) * (uint32_t)(N * 8) + col_bytes[d]);
-        };
-        double2 kw[3][K1];
-        request(std::integral_constant<int, 0>{}, kw);
 
-        // ---- ACC_c itself, rounded to the closest multiple of q / B; the cross stages; re-deal; private transform ---------------
+        // ---- ACC_c itself, rounded to the closest multiple of q / B; the two cross stages; re-deal; private transform -----------
         double x[1][E];
 #pragma unroll
         for (int m = 0; m < E; m++) {
             const uint32_t d = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ bhalf;
             x[0][m] = (double)(int)__builtin_amdgcn_sbfe(d, 0, a.beta);
         }
+        first_butterfly<0>(x[0][0], x[0][2], cw[0]);       // stage 0 pairs register m with m + 2 (node 1)
+        first_butterfly<0>(x[0][1], x[0][3], cw[0]);
 #pragma unroll
-        for (int s = 0; s < LOGW; s++) {
-            const int half = (E / 2) >> s;
-#pragma unroll
-            for (int m = 0; m < E; m++) {
-                if (m & half) continue;
-                const double wv = cw[(1 << s) - 1 + (m >> (LOGE - s))];
-                if (s == 0) {
-                    first_butterfly<0>(x[0][m], x[0][m + half], wv);
-                } else {
-                    const double u = x[0][m], v = fp_mulmod(x[0][m + half], wv);
-                    x[0][m] = u + v;
-                    x[0][m + half] = u - v;
-                }
-            }
+        for (int h = 0; h < 2; h++) {                       // stage 1 pairs m with m + 1 inside each half (nodes 2, 3)
+            const double u = x[0][2 * h], v = fp_mulmod(x[0][2 * h + 1], cw[1 + h]);
+            x[0][2 * h] = u + v;
+            x[0][2 * h + 1] = u - v;
         }
 #pragma unroll
-        for (int q = 0; q < PARTS; q++)
-#pragma unroll
-            for (int r = 0; r < EP; r++) xf[q * M + t + (uint32_t)LANES * r] = x[0][q * EP + r];
+        for (int q = 0; q < PARTS; q++) xf[q * M + t] = x[0][q];
         __syncthreads();
         double *bufs[1] = {xf + w * M};   // the words only this wave reads: its private exchange buffer from here on
 #pragma unroll
         for (int m = 0; m < E; m++) x[0][m] = bufs[0][ln + 64u * m];
-        tw.template forward<1>(x, bufs, ln);
+        LaneNtt256::forward_multi<1, 0>(x, bufs, ln, tw.f, [&] { request(i, Pair1{}, kw1); });
 
-        // ---- the monomial factors: psi^(e o_lane) times the powers of the E-th root the registers differ by -------------------
-        struct Powers {
-            double s0, s1, s2, s3;
-        };
-        auto powers = [&](double base) {
-            if constexpr (E == 8) return Powers{base, fp_mulmod(base, om1), fp_mulmod(base, om2), fp_mulmod(base, om3)};
-            else return Powers{base, fp_mulmod(base, om1), 0.0, 0.0};
-        };
-        const Powers V0 = powers(A[0]), V1 = powers(A[1]), V2 = powers(A[2]);
-        // zeta^e - 1 for register m.  E = 8: m = (r2 r1 r0), k_m = r1 + 2 r0 + 4 r2, root^(t + 4) = -root^t;
-        // E = 4: m = (j1 j0), k_m = j1 + 2 j0, root^(t + 2) = -root^t
-        auto mono = [&](const Powers &V, uint32_t ej, int m) {
-            if constexpr (E == 8) {
-                const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
-                const uint32_t tt = (ej * km) & 7u;                                  // wave-uniform
-                const double v = (tt & 2u) ? ((tt & 1u) ? V.s3 : V.s2) : ((tt & 1u) ? V.s1 : V.s0);
-                return ((tt & 4u) ? -v : v) - 1.0;
-            } else {
-                const uint32_t km = (uint32_t)((m >> 1) | ((m & 1) << 1));
-                const uint32_t tt = (ej * km) & 3u;
-                const double v = (tt & 1u) ? V.s1 : V.s0;
-                return ((tt & 2u) ? -v : v) - 1.0;
-            }
+        // ---- the monomial factors: psi^(e o_lane) and its product with R^e (see above); the sign (-1)^e as a bit operation --------
+        // (Written as selects among +-A, +-A R the compiler builds a table per exponent in SCRATCH memory and indexes it: six
+        // stores and three dependent loads per step, each behind an s_waitcnt vmcnt(0) that also waits for the key words in flight.)
+        double AR[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            const uint32_t r = e[jj] & 3u;                                       // wave-uniform
+            const double re = r == 0u ? 1.0 : r == 1u ? root : r == 2u ? -1.0 : -root;
+            AR[jj] = fp_mulmod(A[jj], re);
+        }
+        // zeta^e - 1 for register m = (j1 j0): k_m = j1 + 2 j0, zeta_m^e = A R^(e k_m): m = 0: A; 1: (-1)^e A; 2: A R^e; 3: (-1)^e A R^e
+        auto mono = [&](int jj, int m) {
+            const double v = (m & 2) ? AR[jj] : A[jj];
+            if (!(m & 1)) return v - 1.0;
+            return __hiloint2double(__double2hiint(v) ^ (int)(e[jj] << 31), __double2loint(v)) - 1.0;
         };
         // ---- bundle x digits, register pair by register pair: products for the three output components (rotated order) ---------
         double prod[K1][E];
@@ -377,25 +371,19 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int m = 2 * j + r;
-                const double mo[3] = {mono(V0, e[0], m), mono(V1, e[1], m), mono(V2, e[2], m)};
+                const double mo[3] = {mono(0, m), mono(1, m), mono(2, m)};
 #pragma unroll
-                for (int c = 0; c < K1; c++) {
+                for (int d = 0; d < K1; d++) {
                     // bundle word: lazy sum of three exact products (< 2.4 q); |x| < 2^49.3, so the product below stays exact
-                    double wsum = fp_mulmod(r ? k[0][c].y : k[0][c].x, mo[0]);
+                    double wsum = fp_mulmod(r ? k[0][d].y : k[0][d].x, mo[0]);
 #pragma unroll
-                    for (int jj = 1; jj < 3; jj++) wsum += fp_mulmod(r ? k[jj][c].y : k[jj][c].x, mo[jj]);
-                    prod[c][m] = fp_mulmod(x[0][m], wsum);
+                    for (int jj = 1; jj < 3; jj++) wsum += fp_mulmod(r ? k[jj][d].y : k[jj][d].x, mo[jj]);
+                    prod[d][m] = fp_mulmod(x[0][m], wsum);
                 }
             }
         };
-#define FBS_K2_PAIR_STEP(J)                                                                                      \
-    if constexpr ((J) < E / 2) {                                                                                 \
-        consume(std::integral_constant<int, (J) < E / 2 ? (J) : 0>{}, kw);                                       \
-        __builtin_amdgcn_sched_barrier(0);   /* (or every request is hoisted to the top, and spilled) */         \
-        if constexpr ((J) + 1 < E / 2) request(std::integral_constant<int, ((J) + 1) % (E / 2)>{}, kw);          \
-    }
-        FBS_K2_PAIR_STEP(0) FBS_K2_PAIR_STEP(1) FBS_K2_PAIR_STEP(2) FBS_K2_PAIR_STEP(3)
-#undef FBS_K2_PAIR_STEP
+        consume(Pair0{}, kw0);
+        consume(Pair1{}, kw1);
 
         // ---- hand the other two components theirs; sum; private inverse; re-deal back; joining stages; accumulate ---------------
 #pragma unroll
@@ -407,25 +395,25 @@ __global__ __launch_bounds__(192 << LOGW) void k_blind_rotate_cu_k2(BrArgs a) {
         double own[E];
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] = prod[0][m] + mine[64u * m + ln] + mine2[64u * m + ln];
-        tw.inverse(own, mine, ln, typename Part::NoHook{});   // three products below 0.8 q each: centred first by the transform
+        request(i_next, Pair0{}, kw0);   // the NEXT step's first register pair: it streams in behind the inverse transform
+        tw.inverse(own, mine, ln, LaneNtt256::NoHook{});   // three products below 0.8 q each: centred first by the transform
         Part::sync();
 #pragma unroll
         for (int m = 0; m < E; m++) mine[ln + 64u * m] = own[m];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PARTS; q++)
+        for (int q = 0; q < PARTS; q++) own[q] = back[q * M + t];
 #pragma unroll
-            for (int r = 0; r < EP; r++) own[q * EP + r] = back[q * M + t + (uint32_t)LANES * r];
+        for (int h = 0; h < 2; h++) {                       // the two joining stages (Gentleman-Sande: nodes 2, 3, then node 1)
+            const double u = own[2 * h], v = own[2 * h + 1];
+            own[2 * h] = u + v;
+            own[2 * h + 1] = fp_mulmod(u - v, iw[1 + h]);
+        }
 #pragma unroll
-        for (int s = LOGW - 1; s >= 0; s--) {
-            const int half = (E / 2) >> s;
-#pragma unroll
-            for (int m = 0; m < E; m++) {
-                if (m & half) continue;
-                const double u = own[m], v = own[m + half];
-                own[m] = u + v;
-                own[m + half] = fp_mulmod(u - v, iw[(1 << s) - 1 + (m >> (LOGE - s))]);
-            }
+        for (int m = 0; m < 2; m++) {
+            const double u = own[m], v = own[m + 2];
+            own[m] = u + v;
+            own[m + 2] = fp_mulmod(u - v, iw[0]);
         }
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
@@ -453,23 +441,18 @@ bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
     const fbs_params &p = ctx->p;
     if (p.k != 2 || p.log_n_poly != 10 || ctx->group != 2 || p.l_bsk != 1) return false;
     const size_t cus = (size_t)ctx->cu_count;
-    // tune.br_k2_shape: 0 = by launch size (below); 3 = always the three-waves-per-bootstrap kernels; 12 / 6 = always the
-    // twelve- / six-wave whole-workgroup shape (A/B measurements, dispatch tests)
+    // tune.br_k2_shape: 0 = by launch size (below); 3 = always the three-waves-per-bootstrap kernels; 12 = always the twelve-wave
+    // whole-workgroup shape (A/B measurements, dispatch tests)
     const int64_t shape = ctx->tune.br_k2_shape;
-    const bool small = a.count <= cus * (size_t)ctx->tune.br_cu_max_per_cu && ctx->tune.br_cu_kernel;
+    const bool small = a.count <= cus * K2_CU_ROUNDS && ctx->tune.br_cu_kernel && ctx->tune.br_cu_max_per_cu >= 1;
     if ((shape == 12 || (shape == 0 && small)) && ctx->d_bsk_hat_small) {
-        // launches that leave most of the chip empty: one bootstrap on twelve waves (round after round beyond one per CU)
+        // launches of up to three bootstraps per CU: one bootstrap on twelve waves, round after round (n = 734, one box: 2.06 ms at
+        // 64, 2.36 at 256, 4.43 at 512, 6.37 at 768 bootstraps against 3.33 / 3.49 / 4.92 / 6.79 on three waves per bootstrap;
+        // from 769 on a round of four-bootstrap workgroups is ahead: 6.8-7.2 ms up to 1 024)
         BrArgs b = a;
         b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
-        *kernel = "k_blind_rotate_cu_k2<2>";
-        hipLaunchKernelGGL((k_blind_rotate_cu_k2<2>), dim3((unsigned)a.count), dim3(768), 0, stream, b);
-        return true;
-    }
-    if (shape == 6 && ctx->d_bsk_hat_mid) {
-        BrArgs b = a;
-        b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_mid);
-        *kernel = "k_blind_rotate_cu_k2<1>";
-        hipLaunchKernelGGL((k_blind_rotate_cu_k2<1>), dim3((unsigned)a.count), dim3(384), 0, stream, b);
+        *kernel = "k_blind_rotate_cu_k2";
+        hipLaunchKernelGGL(k_blind_rotate_cu_k2, dim3((unsigned)a.count), dim3(768), 0, stream, b);
         return true;
     }
     // the three-waves-per-bootstrap kernel: up to one bootstrap per CU one per workgroup; up to two: two; beyond: four
@@ -487,29 +470,8 @@ bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
     return true;
 }
 
-// the key in the evaluation order of WavesNtt<10, 1> (two waves per polynomial, 512-point parts): what k_blind_rotate_cu_k2<1> reads
-__global__ __launch_bounds__(128) void k_bsk_transform_two_waves(const uint64_t *__restrict__ src, double *__restrict__ dst,
-                                                                 const double *__restrict__ tw_fwd, double n_inv, size_t polys) {
-    using W = WavesNtt<10, 1>;
-    __shared__ double lds[2 * W::N];
-    const uint32_t t = threadIdx.x;
-    typename W::Xchg xc{lds, 0};
-    for (size_t p = blockIdx.x; p < polys; p += gridDim.x) {   // uniform trip count per workgroup
-        double x[W::E];
-#pragma unroll
-        for (int m = 0; m < W::E; m++) x[m] = fp_from_u64(src[p * W::N + W::template index_of<0>(t, m)]);
-        W::forward(x, xc, t, Twiddles(tw_fwd + W::LANE_TABLE_OFFSET, tw_fwd));
-#pragma unroll
-        for (int m = 0; m < W::E; m++) dst[p * W::N + W::key_word(t, m)] = fp_center(fp_mulmod(x[m], n_inv));
-    }
-}
-void launch_bsk_transform_two_waves(const uint64_t *d_src, double *d_dst, const double *tw_fwd, double n_inv, size_t polys, hipStream_t stream) {
-    hipLaunchKernelGGL(k_bsk_transform_two_waves, dim3((unsigned)std::min<size_t>(polys, 4096)), dim3(128), 0, stream, d_src, d_dst, tw_fwd, n_inv, polys);
-}
-
 void blind_rotate_k2_catalog(std::vector<std::string> *out) {
-    for (const char *name : {"k_blind_rotate_pairs_k2<10,1>", "k_blind_rotate_pairs_k2<10,2>", "k_blind_rotate_pairs_k2<10,4>", "k_blind_rotate_cu_k2<2>",
-                             "k_blind_rotate_cu_k2<1>"})
+    for (const char *name : {"k_blind_rotate_pairs_k2<10,1>", "k_blind_rotate_pairs_k2<10,2>", "k_blind_rotate_pairs_k2<10,4>", "k_blind_rotate_cu_k2"})
         out->push_back(name);
 }
 

@@ -209,7 +209,6 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     ctx->tune.br_cu_kernel = getenv("FBS_BR_NO_CU_KERNEL") ? 0 : 1;
     ctx->tune.br_cu_max_per_cu = env_knob("FBS_BR_CU_MAX_PER_CU", ctx->tune.br_cu_max_per_cu);
     ctx->tune.br_cu_lean = env_knob("FBS_BR_CU_LEAN", ctx->tune.br_cu_lean);
-    ctx->tune.br_k2_mid_copy = env_knob("FBS_BR_K2_MID_COPY", ctx->tune.br_k2_mid_copy);
     ctx->tune.br_k2_shape = env_knob("FBS_BR_K2_SHAPE", ctx->tune.br_k2_shape);
     const fbs_params &p = ctx->p;
     if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
@@ -311,7 +310,7 @@ void fbs_ctx_destroy(fbs_ctx *ctx) try {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch_used) (void)hipStreamSynchronize(ctx->scratch_stream);
-    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_bsk_hat_mid, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_ks_a, (void *)ctx->d_ks_b, (void *)ctx->d_ks_c, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc, (void *)ctx->d_stage_in, (void *)ctx->d_stage_out, (void *)ctx->d_stage_ids,
+    for (void *p : {(void *)ctx->d_bsk_hat, (void *)ctx->d_bsk_hat_small, (void *)ctx->d_ksk, (void *)ctx->d_ksk_f, (void *)ctx->d_ks_corr, (void *)ctx->d_ks_a, (void *)ctx->d_ks_b, (void *)ctx->d_ks_c, (void *)ctx->d_tw_fwd, (void *)ctx->d_tw_inv, (void *)ctx->d_psi_pow, (void *)ctx->d_ms, (void *)ctx->d_ms_eps, (void *)ctx->d_ms_body, (void *)ctx->d_acc, (void *)ctx->d_stage_in, (void *)ctx->d_stage_out, (void *)ctx->d_stage_ids,
                     (void *)ctx->d_idx, (void *)ctx->d_wires})
         if (p) (void)hipFree(p);
     if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);

@@ -44,8 +44,7 @@ struct Tune {
     int64_t br_cu_kernel = 1;       // 0: no one-bootstrap-per-CU kernel (the generic kernel on the four-wave transform instead)
     int64_t br_cu_max_per_cu = 2;   // bootstraps per CU up to which a launch takes the one-bootstrap-per-CU kernel
     int64_t br_cu_lean = 1;         // 1: between one and two per CU, its 128-register variant (two workgroups per CU); 2: always; 0: never
-    int64_t br_k2_mid_copy = 0;     // k = 2: also keep the key in the six-wave shape's order (FBS_BR_K2_MID_COPY=1 at context creation)
-    int64_t br_k2_shape = 0;        // k = 2: 0 by launch size; 3 always three waves per bootstrap; 12 / 6 always the whole-workgroup latency shape
+    int64_t br_k2_shape = 0;        // k = 2: 0 by launch size; 3 always three waves per bootstrap; 12 always the twelve-wave latency shape
 };
 
 // ---- launch descriptors ------------------------------------------------------------------------
@@ -122,7 +121,6 @@ struct fbs_ctx {
     std::vector<uint64_t> sk_lwe, sk_glwe, bsk, ksk;   // host copies, standard layout
 
     uint64_t *d_bsk_hat = nullptr;   // [n][rows][k+1][N]  NTT domain, lane-interleaved, x N^-1
-    uint64_t *d_bsk_hat_mid = nullptr;     // k = 2 only: the same in the evaluation order of two waves per polynomial (k_blind_rotate_cu_k2<1>), or null
     uint64_t *d_bsk_hat_small = nullptr;   // the same in the evaluation order of the small-launch shape (fbs_ntt.hpp), or null
     uint64_t *d_ksk = nullptr;       // [D*t][ksk_stride]
     uint64_t *d_ksk_f = nullptr;     // the same key as centred doubles (bit patterns), for the FP64 key-switch kernel

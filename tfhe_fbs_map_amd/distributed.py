@@ -33,8 +33,8 @@ import torch
 import torch.distributed as dist
 
 
-from .schedule import (LAUNCH_MS_P1024, ROUND_MS_P1024, allgather_ms, choose_sharding, launch_ms, plan_levels,  # noqa: F401  (re-exported)
-                       split_range)
+from .schedule import (LAUNCH_FAMILIES, LAUNCH_MS_P1024, ROUND_MS_P1024, allgather_ms, choose_sharding, launch_family,  # noqa: F401  (re-exported)
+                       launch_ms, plan_levels, split_range)
 
 
 # --------------------------------------------------------------------------------------------

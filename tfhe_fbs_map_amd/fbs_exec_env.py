@@ -113,13 +113,13 @@ class ExecConfig:
     # times the noise variance, so the parameter set is chosen for the program's FUSED norm and its cost times the rotations
     # left is compared with the unfused choice.  With explicit `params` None means off (their margin is the caller's).
     fuse_tables: bool | None = None
-    # GLWE dimensions the selector may use.  k = 2 (N = 1024, two key bits per step: k_blind_rotate_pairs_k2) is 0.81 of the k = 1
-    # sets' cost per bootstrap in launches of a round (1 024 bootstraps) or more and ahead from ~400 per launch (512: 5.06 against
-    # 5.35 ms); up to one bootstrap per CU the k = 1 sets' whole-CU kernels are faster (2.8 against 3.6 ms per launch).  `choose`
-    # admits it for programs whose levels average `wide_level` bootstraps (gates of the level x samples) or more, and only without
-    # shared rotations (built for k = 1).
+    # GLWE dimensions the selector may use.  k = 2 (N = 1024, two key bits per step) carries what the k = 1 sets need N = 2048 for
+    # at 0.81 of their cost per bootstrap in launches of a round (1 024 bootstraps) or more (k_blind_rotate_pairs_k2), and since
+    # round 4 it is ahead at EVERY launch size: one bootstrap on the twelve waves of a workgroup (k_blind_rotate_cu_k2) takes
+    # 2.0-2.4 ms per launch of up to one bootstrap per CU where the k = 1 sets' whole-CU kernels take 2.6-2.9.  So the choice no
+    # longer depends on how wide a program's levels are (rounds 3's `wide_level`), nor on how many ranks it is cut over: every
+    # rank of a sharded run derives the same set from (p, norm2).  Shared rotations (fuse_tables) are built for k = 1 only.
     glwe_dims: tuple = (1, 2)
-    wide_level: int = 400
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)
@@ -130,9 +130,9 @@ class ExecConfig:
             self.seed = os.urandom(32)
         return self.seed
 
-    def params_choice(self, p, norm2=1, wide=False):
-        """The parameter set a program with plaintext modulus p and noise statistic norm2 is evaluated with (`wide`: its levels are
-        launches of a round or more, see `glwe_dims`)."""
+    def params_choice(self, p, norm2=1, glwe_dims=None):
+        """The parameter set a program with plaintext modulus p and noise statistic norm2 is evaluated with (`glwe_dims`: the GLWE
+        dimensions admitted for it; default: this configuration's)."""
         from .params import REFERENCE_MARGIN, choose_params, params_for
         if self.params is None and self.reduced_noise:
             return params_for(p)
@@ -140,7 +140,7 @@ class ExecConfig:
             floor = None if self.allow_margin_floor is None else min(self.min_margin, self.allow_margin_floor)
             try:
                 return choose_params(p, norm2, min_margin=self.min_margin, security=self.security, floor_margin=floor,
-                                     glwe_dims=tuple(self.glwe_dims) if wide else (1,))
+                                     glwe_dims=tuple(self.glwe_dims if glwe_dims is None else glwe_dims))
             except ValueError as e:
                 if floor is not None:
                     raise
@@ -159,33 +159,30 @@ class ExecConfig:
     def context_for(self, p, norm2=1):
         return self.context_of(self.params_choice(p, norm2))
 
-    def choose(self, env, p, samples=None):
+    def choose(self, env, p, samples=None, ranks=1):
         """(context, fuse) for a program: the parameter set of `params_choice` at the program's norm, and whether the
-        tables of shared sources share their blind rotation (`fuse_tables`).  `samples`: how many samples it is about to be
-        evaluated on (decides whether its levels are wide enough for the k = 2 sets).  Leaves in `last_choice` the margin the
-        program got and the failure probability that goes with it."""
+        tables of shared sources share their blind rotation (`fuse_tables`).  `samples` / `ranks`: how many samples it is about
+        to be evaluated on, over how many GPUs -- recorded in `last_choice` with the launch sizes they imply; they do not move
+        the parameter set (see `glwe_dims`: k = 2 is ahead at every launch size, so one GPU and every rank of a sharded run take
+        the same set).  Leaves in `last_choice` the margin the program got and the failure probability that goes with it."""
         from .params import bootstrap_cost
         stats = env.stats()
-        wide = False
-        if samples and 2 in self.glwe_dims and stats["nb_bootstrap"]:
-            from .schedule import plan_levels
-            depth = max(1, plan_levels(env.lower())["depth"])
-            wide = stats["nb_bootstrap"] * int(samples) >= self.wide_level * depth
         fstats = env.fusion_stats(p) if self.fuse_tables is not False else None
         if fstats is None or fstats["nb_rotation"] == stats["nb_bootstrap"] or (self.fuse_tables is None and self.params is not None):
-            return self._chosen(self.params_choice(p, stats["norm2_linprod"], wide), False, stats["norm2_linprod"], stats["nb_bootstrap"])
-        fused = self.params_choice(p, fstats["norm2_linprod"])
+            return self._chosen(self.params_choice(p, stats["norm2_linprod"]), False, stats["norm2_linprod"], stats["nb_bootstrap"], samples, ranks)
+        fused = self.params_choice(p, fstats["norm2_linprod"], glwe_dims=(1,))      # shared rotations: k = 1
         if self.fuse_tables is not True:
-            plain = self.params_choice(p, stats["norm2_linprod"], wide)
+            plain = self.params_choice(p, stats["norm2_linprod"])
             if not bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]:
-                return self._chosen(plain, False, stats["norm2_linprod"], stats["nb_bootstrap"])
-        return self._chosen(fused, True, fstats["norm2_linprod"], stats["nb_bootstrap"])
+                return self._chosen(plain, False, stats["norm2_linprod"], stats["nb_bootstrap"], samples, ranks)
+        return self._chosen(fused, True, fstats["norm2_linprod"], stats["nb_bootstrap"], samples, ranks)
 
-    def _chosen(self, prm, fuse, norm2, nb_bootstrap):
+    def _chosen(self, prm, fuse, norm2, nb_bootstrap, samples=None, ranks=1):
         from .params import margin_sigmas, p_error
         margin = margin_sigmas(prm, norm2)
         per_bootstrap = p_error(margin)
         self.last_choice = dict(params=prm, fuse_tables=fuse, norm2=norm2, margin_sigmas=margin, asked_margin=self.min_margin,
+                                samples=samples, ranks=ranks,
                                 p_error_per_bootstrap=per_bootstrap,
                                 p_error_per_sample=-math.expm1(nb_bootstrap * math.log1p(-min(per_bootstrap, 0.5))),
                                 relaxed=self.params is None and not self.reduced_noise and margin < self.min_margin - 1e-9)

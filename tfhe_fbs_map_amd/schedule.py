@@ -61,26 +61,62 @@ def split_range(total, parts, r):
 # --------------------------------------------------------------------------------------------
 # how to cut a program over G ranks
 # --------------------------------------------------------------------------------------------
-# One key switch + blind rotation launch of `count` bootstraps on one MI355X at the benchmark shape P1024, in ms
-# (profiles/r03/batch_sweep.txt, the buffer-load kernels).  Up to one bootstrap per CU a launch costs the latency of one bootstrap on a whole CU
-# (k_blind_rotate_cu), up to two that of two workgroups sharing a CU, then the small workgroups, then whole rounds of four per
-# CU; beyond a round, rounds + remainder.
+# One key switch + blind rotation launch of `count` bootstraps on one MI355X, in ms, per kernel FAMILY: which kernels a parameter
+# set runs on decides the shape of its staircase, the number of blind-rotation steps scales it.  Up to one bootstrap per CU a
+# launch costs the latency of one bootstrap on a whole CU, then come the shapes for two and three per CU, then whole rounds of
+# four per CU; beyond a round, rounds + remainder.  Measured (profiles/r04/launch_staircases.txt; r03/batch_sweep.txt for P1024):
+#   "p1024"     k = 1, N = 1024, one key bit per step, three levels, n = 630 (BASELINE's benchmark shape): k_blind_rotate_cu /
+#               its lean variant / small workgroups / k_blind_rotate<10,6,3,4>
+#   "k2"        k = 2, N = 1024, two key bits per step, n = 734 (the default 128-bit sets for p <= 15 at small norms):
+#               k_blind_rotate_cu_k2 for one, two, three rounds of one bootstrap per CU, k_blind_rotate_pairs_k2<10,4> beyond
+#   "n2048"     k = 1, N = 2048, two key bits per step, one level, n = 714 (p = 15 at heavy norms; shared rotations):
+#               k_blind_rotate_cu_pairs<11,1> up to one per CU, k_blind_rotate_pairs<11,7,4> beyond
+#   "n2048_l2"  the same with two levels, n = 766 (p = 31, BASELINE configs[4]): k_blind_rotate_cu_pairs<11,2>, round after round
 LAUNCH_MS_P1024 = ((1, 2.91), (128, 2.92), (256, 3.14), (257, 5.46), (512, 5.53), (513, 8.21), (768, 8.21), (769, 9.29), (1024, 9.29))
 ROUND_MS_P1024 = 9.20      # per further round of 1024 in a long launch (8192 bootstraps: 73.8 ms)
+LAUNCH_FAMILIES = {
+    "p1024": dict(steps=630, stairs=LAUNCH_MS_P1024, round_ms=ROUND_MS_P1024, full_from=896),
+    "k2": dict(steps=367, stairs=((1, 2.06), (128, 2.11), (256, 2.36), (257, 4.34), (512, 4.43), (513, 6.37), (768, 6.37), (769, 6.79), (896, 6.89),
+                                  (1024, 7.22)), round_ms=7.22, full_from=769),
+    "n2048": dict(steps=357, stairs=((1, 2.61), (128, 2.65), (256, 2.89), (257, 5.35), (512, 5.35), (513, 7.9), (768, 8.0), (769, 9.25), (1024, 9.25)),
+                  round_ms=9.2, full_from=896),
+    "n2048_l2": dict(steps=383, stairs=((1, 4.27), (256, 4.61), (257, 8.7), (512, 8.7), (513, 13.0), (768, 13.0), (769, 16.6), (1024, 16.6)),
+                     round_ms=16.6, full_from=769),
+}
 
 
-def launch_ms(count, cost=1.0):
-    """Modelled time of one bootstrap launch of `count` ciphertexts; `cost` = params.bootstrap_cost of the parameter set."""
+def launch_family(params):
+    """-> (family name, scale): the staircase a parameter set's launches follow and the factor on its times (blind-rotation steps
+    over the steps of the set the staircase was measured at).  Shapes without a measured staircase of their own take P1024's,
+    scaled by the modelled cost of a bootstrap (params.bootstrap_cost)."""
+    steps = params.n // 2 if params.bsk_group == 2 else params.n
+    if params.k == 2:
+        name = "k2"
+    elif params.N == 2048 and params.bsk_group == 2 and params.l_bsk <= 2:
+        name = "n2048" if params.l_bsk == 1 else "n2048_l2"
+    elif params.N == 1024 and params.bsk_group != 2 and params.l_bsk == 3:
+        name = "p1024"
+    else:
+        from .params import bootstrap_cost
+        return "p1024", bootstrap_cost(params)
+    return name, steps / LAUNCH_FAMILIES[name]["steps"]
+
+
+def launch_ms(count, cost=1.0, params=None):
+    """Modelled time of one bootstrap launch of `count` ciphertexts.  `params`: the parameter set (its own kernel family's
+    staircase, `launch_family`); without it the P1024 staircase times `cost` = params.bootstrap_cost of the set."""
     if count <= 0:
         return 0.0
+    name, scale = launch_family(params) if params is not None else ("p1024", cost)
+    fam = LAUNCH_FAMILIES[name]
     rounds, rest = divmod(int(count), 1024)
-    if rounds and rest >= 896:
+    if rounds and rest >= fam["full_from"]:
         rounds, rest = rounds + 1, 0
-    ms = rounds * ROUND_MS_P1024 + (0.2 if rounds == 1 and not rest else 0.0)
+    ms = rounds * fam["round_ms"] + (0.2 if name == "p1024" and rounds == 1 and not rest else 0.0)
     if rest:
-        xs, ys = zip(*LAUNCH_MS_P1024)
+        xs, ys = zip(*fam["stairs"])
         ms += float(np.interp(rest, xs, ys))
-    return ms * cost
+    return ms * scale
 
 
 def allgather_ms(rows_per_rank, ranks, ct_bytes=8200, link_GBps=153.0, efficiency=0.8, latency_us=30.0):
@@ -93,7 +129,7 @@ def allgather_ms(rows_per_rank, ranks, ct_bytes=8200, link_GBps=153.0, efficienc
     return latency_us * 1e-3 + per_link / (link_GBps * 1e9 * efficiency) * 1e3
 
 
-def choose_sharding(level_width, T, world, cost=1.0, ct_bytes=8200):
+def choose_sharding(level_width, T, world, cost=1.0, ct_bytes=None, params=None):
     """How to lay `world` ranks over a program's two independent axes (fbs_mapper/fbs_exec_env.py:211-223): `sample_groups`
     groups that each take a slice of the T samples through the whole program (no communication), times `gate_groups` ranks
     per group that cut every level's (gate, sample) batch among themselves (one all-gather per level).
@@ -101,20 +137,24 @@ def choose_sharding(level_width, T, world, cost=1.0, ct_bytes=8200):
     Per level every rank ends up with about width * T / world bootstraps whichever way the cut goes, so what decides is
     (i) whether there are samples enough to cut (T < world forces gate groups), (ii) the collectives gate groups pay, and
     (iii) how the slices fall on the launch-time staircase (`launch_ms`: a slice of 257 bootstraps costs two rounds of the
-    one-bootstrap-per-CU kernel, 256 cost one).  All divisor pairs of `world` are priced; ties go to fewer collectives.
+    one-bootstrap-per-CU kernel, 256 cost one) -- the staircase of the parameter set actually loaded when `params` is given
+    (its kernel family's: `launch_family`), P1024's times `cost` otherwise.  All divisor pairs of `world` are priced; ties go
+    to fewer collectives.
     -> dict(sample_groups, gate_groups, predicted_ms, single_gpu_ms, candidates)."""
     level_width = [int(w) for w in level_width]
+    if ct_bytes is None:
+        ct_bytes = 8200 if params is None else 8 * (params.k * params.N + 1)
     cands = []
     for gs in range(1, world + 1):
         if world % gs or gs > max(1, T):
             continue
         gg = world // gs
         samples = -(-T // gs)
-        compute = sum(launch_ms(-(-w * samples // gg), cost) for w in level_width)
+        compute = sum(launch_ms(-(-w * samples // gg), cost, params) for w in level_width)
         comm = sum(allgather_ms(-(-w * samples // gg), gg, ct_bytes) for w in level_width) if gg > 1 else 0.0
         cands.append(dict(sample_groups=gs, gate_groups=gg, compute_ms=compute, allgather_ms=comm, predicted_ms=compute + comm))
     best = min(cands, key=lambda c: (round(c["predicted_ms"], 6), c["gate_groups"]))
-    single = sum(launch_ms(w * T, cost) for w in level_width)
+    single = sum(launch_ms(w * T, cost, params) for w in level_width)
     return dict(sample_groups=best["sample_groups"], gate_groups=best["gate_groups"], predicted_ms=best["predicted_ms"],
                 single_gpu_ms=single, predicted_speedup=single / best["predicted_ms"] if best["predicted_ms"] else 1.0, candidates=cands)
 

@@ -1,11 +1,10 @@
 """The launch shapes of GLWE dimension k = 2 side by side (csrc/fbs_blind_rotate_k2.hip): three waves per bootstrap
-(k_blind_rotate_pairs_k2<10, 1 | 2 | 4>) against ONE bootstrap on the twelve / six waves of a workgroup (k_blind_rotate_cu_k2<2 | 1>).
+(k_blind_rotate_pairs_k2<10, 1 | 2 | 4>) against ONE bootstrap on the twelve waves of a workgroup (k_blind_rotate_cu_k2).
 First every shape word for word against the oracle at toy n (ragged batches, every table mode, trivial and maximal ciphertexts),
 then per-launch times at the 128-bit set the selector ships for (15, 70) with the outputs decrypted and a few ciphertexts held to
-the oracle.      FBS_BR_K2_MID_COPY=1 python3 tools/k2_shapes.py [steps = 5] [sizes ...]"""
+the oracle.      python3 tools/k2_shapes.py [steps = 5] [sizes ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("FBS_BR_K2_MID_COPY", "1")
 import numpy as np
 import torch
 from tfhe_fbs_map_amd import Context, Params, choose_params
@@ -13,7 +12,7 @@ from oracle import tfhe_oracle as orc
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 sizes = [int(v) for v in sys.argv[2:]] or [64, 128, 256, 300, 384, 512, 768, 1024]
-SHAPES = {3: "three waves per bootstrap", 12: "twelve waves per bootstrap", 6: "six waves per bootstrap"}
+SHAPES = {3: "three waves per bootstrap", 12: "twelve waves per bootstrap"}
 bad = 0
 tabs = [[0, 1, 1, 0, 1, 0, 0], [0, 1, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1], [0, 1, 2, 3, 2, 1, 0], [1, 1, 1, 0, 1, 0, 0, 1, 1, 1]]
 for beta in (21, 17):

@@ -58,7 +58,8 @@ def measure(name, T, ranks_list, all_ranks, secure):
     p = int(name.rsplit("_p", 1)[-1])
     if secure:
         from tfhe_fbs_map_amd import choose_params
-        # (--secure k2: GLWE dimension 2 admitted -- for programs whose per-RANK slices of a level are still a round or more)
+        # (--secure k2: GLWE dimension 2 admitted, as ExecConfig does for every program since the twelve-wave latency shape made
+        # it the faster choice at every launch size: one GPU and every rank run the SAME set; --secure k1: the k = 1 sets only)
         prm = choose_params(p, env.stats()["norm2_linprod"], glwe_dims=(1, 2) if secure == "k2" else (1,))
     else:
         prm = params_for(p)
@@ -79,7 +80,7 @@ def measure(name, T, ranks_list, all_ranks, secure):
 
     layouts, chosen = {}, {}
     for G in ranks_list:
-        pick = choose_sharding(widths, T, G)
+        pick = choose_sharding(widths, T, G, params=prm)     # priced on the staircase of the set actually loaded
         for label, gs in (("gate", 1), ("sample", G if T >= G else None), ("chosen", pick["sample_groups"])):
             if gs is not None and (label != "chosen" or (gs, G // gs) not in [v for (g, _), v in layouts.items() if g == G]):
                 layouts[(G, label)] = (gs, G // gs)
@@ -135,7 +136,7 @@ def measure(name, T, ranks_list, all_ranks, secure):
     ok = all(bool(np.array_equal(out[k], clear[k])) for k, w in enumerate(low["out_wire"]) if w >= 0)
     single_ms = sum(x["lincomb_ms"] + x["bootstrap_ms"] for x in single)
     result = dict(circuit=name, stands_for=CONFIGS.get(name, ""), samples=T, depth=prog.depth, bootstraps=prog.n_bootstrap * T,
-                  level_widths=widths, params=dict(n=prm.n, N=prm.N, l=prm.l_bsk, beta=prm.beta_bsk, key_bits_per_step=prm.bsk_group),
+                  level_widths=widths, params=dict(n=prm.n, N=prm.N, k=prm.k, l=prm.l_bsk, beta=prm.beta_bsk, key_bits_per_step=prm.bsk_group),
                   outputs_equal_cleartext=ok, choose_sharding={str(g): dict(sample_groups=v[0], gate_groups=v[1], predicted_speedup=v[2])
                                                                 for g, v in chosen.items()},
                   single_gpu_ms=single_ms, single_gpu_fbs_per_s=prog.n_bootstrap * T / single_ms * 1e3,
