@@ -77,6 +77,12 @@ __device__ __forceinline__ void favour(bool me) {
 // LEAN: the variant for launches of between one and two bootstraps per CU -- 128 registers per thread, so that two workgroups
 // share a CU and fill each other's barrier and LDS stalls: the partner component's key words and the inverse twiddles are
 // requested after the forward transforms instead of being held through them.
+// FBS_CU_PREFETCH: the key words of step i + 1 requested during step i, behind its hand-over barrier (a step's key rows do not
+// depend on its data): they stream in behind the inverse transform instead of the next step's rotation and digits.  Measured
+// (tools/cu_latency.py, one box, per launch of 64 / 256 bootstraps at P1024): 2.86 / 3.12 -> 2.80 / 3.05 ms.
+#ifndef FBS_CU_PREFETCH
+#define FBS_CU_PREFETCH 1
+#endif
 template <int LOGN, int NL, int FIRST, bool LEAN = false>
 __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_rotate_cu(BrArgs a) {
     using W = WavesNtt<LOGN, 2>;
@@ -140,26 +146,37 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     uint32_t r_next = ms[0];
     const bool second = comp != 0u;   // this wave belongs to component 1 (scalar)
-    FBS_TRACE_INIT
-    for (uint32_t i = 0; i < a.n; i++) {
-        const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
-        r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
-        if (r == 0) continue;   // X^0 * ACC - ACC = 0 (uniform over the workgroup: no barrier is skipped by part of it)
-        FBS_TRACE(0)
-
-        // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
-        // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
-        double2 ko[NL][E / 2], kt[NL][E / 2];
-        const KeyRows keys(a.bsk_hat + ((size_t)i * rows + comp * NL) * 2 * N);   // (buffer loads: fbs_blind_rotate.hpp)
+    constexpr bool PREFETCH = FBS_CU_PREFETCH != 0 && !LEAN;
+    double2 ko[NL][E / 2], kt[NL][E / 2];
+    auto request_keys = [&](uint32_t step) {
+        const KeyRows rows_of(a.bsk_hat + ((size_t)step * rows + comp * NL) * 2 * N);
 #pragma unroll
         for (int lv = 0; lv < NL; lv++) {
             const uint32_t k_own = ((uint32_t)lv * 2u + comp) * (uint32_t)(N * 8), k_oth = ((uint32_t)lv * 2u + (comp ^ 1u)) * (uint32_t)(N * 8);
 #pragma unroll
             for (int j = 0; j < E / 2; j++) {
-                ko[lv][j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_own);
-                if constexpr (!LEAN) kt[lv][j] = keys.load(t16 + (uint32_t)(j * LANES * 16), k_oth);
+                ko[lv][j] = rows_of.load(t16 + (uint32_t)(j * LANES * 16), k_own);
+                if constexpr (!LEAN) kt[lv][j] = rows_of.load(t16 + (uint32_t)(j * LANES * 16), k_oth);
             }
         }
+    };
+    if constexpr (PREFETCH) request_keys(0);
+    FBS_TRACE_INIT
+    for (uint32_t i = 0; i < a.n; i++) {
+        const uint32_t r = __builtin_amdgcn_readfirstlane(r_next);
+        r_next = ms[i + 1];     // ms has n+1 entries; the last one (the body) is read here and ignored
+        const uint32_t i_next = i + 1 < a.n ? i + 1 : i;
+        if (r == 0) {           // X^0 * ACC - ACC = 0 (uniform over the workgroup: no barrier is skipped by part of it)
+            if constexpr (PREFETCH) request_keys(i_next);
+            continue;
+        }
+        FBS_TRACE(0)
+
+        // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
+        // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
+        // (FBS_CU_PREFETCH: requested during the step BEFORE instead, behind its hand-over barrier)
+        const KeyRows keys(a.bsk_hat + ((size_t)i * rows + comp * NL) * 2 * N);   // (buffer loads: fbs_blind_rotate.hpp)
+        if constexpr (!PREFETCH) request_keys(i);
 
         // ---- (X^r - 1) * ACC_c, centred, rounded to the closest multiple of q / B^l; packed balanced digits -------------
         uint32_t digits[E];
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
             if constexpr (!LEAN) favour<2>(second);
 #pragma unroll
             for (int m = 0; m < E; m++) own[m] += accbuf[(uint32_t)LANES * m + t];
+            if constexpr (PREFETCH) request_keys(i_next);   // the NEXT step's key words stream in behind the inverse transform
             // ---- private inverse, re-deal back -----------------------------------------------------------------------
             tw.inverse(own, bufs[0], ln, [&] {
                 if constexpr (!LEAN) favour<2>(!second);
@@ -332,6 +350,13 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
 // NL gadget levels (1: the p = 15 sets; 2: what p = 31 takes with two key bits per step): the levels' forward transforms run
 // together (forward_multi), and the key words -- 6 NL polynomials per component and step -- are fetched register pair by
 // register pair while the bundle of the pair before is built, instead of being held through the transforms.
+// FBS_CU_PAIRS_PREFETCH: the first register pair's key words of step i + 1 requested during step i, behind its hand-over barrier
+// (k_blind_rotate_cu_k2, fbs_blind_rotate_k2.hip, has the measurements of this order at k = 2, where it is worth 15 %).  Here, per
+// launch of 64 / 256 bootstraps (tools/cu_latency.py, one box): one level (128-bit p = 15 set, n = 714) 2.63 / 2.90 -> 2.56 / 2.82 ms;
+// two levels (p = 31, n = 766) 4.10 / 4.40 -> 4.15 / 4.46 ms and 16.53 -> 16.73 per 1 024 -- so it is on for one level only.
+#ifndef FBS_CU_PAIRS_PREFETCH
+#define FBS_CU_PAIRS_PREFETCH 1
+#endif
 template <int LOGN, int NL>
 __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     using W = WavesNtt<LOGN, 2>;
@@ -393,7 +418,27 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
 
     const uint32_t t16 = t * 16u;   // this thread's 16 bytes of a register pair's 16 LANES
     const uint32_t n_pairs = a.n / 2;
+    // (the key words of one register pair (2j, 2j + 1) of a step: three samples x NL rows, of the own or of the partner's column)
+    auto request_at = [&](uint32_t step, auto jc, auto partner, double2 (&k)[3][NL]) {
+        constexpr int j = decltype(jc)::value;
+        const KeyRows keys(a.bsk_hat + (size_t)step * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N);   // (buffer loads: fbs_blind_rotate.hpp)
+        const uint32_t col = decltype(partner)::value ? comp ^ 1u : comp;
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+            for (int lv = 0; lv < NL; lv++)
+                k[jj][lv] = keys.load(t16 + (uint32_t)(j * LANES * 16), ((uint32_t)(jj * (int)rows + lv) * 2u + col) * (uint32_t)(N * 8));
+    };
+    using Own = std::false_type;
+    using Oth = std::true_type;
+    using Pair0 = std::integral_constant<int, 0>;
+    constexpr bool PAIRS_PREFETCH = FBS_CU_PAIRS_PREFETCH != 0 && NL == 1;
     uint32_t e0_next = ms[0], e1_next = ms[1];
+    double2 ko[3][NL], kt[3][NL];
+    if constexpr (PAIRS_PREFETCH) {
+        request_at(0, Pair0{}, Own{}, ko);
+        request_at(0, Pair0{}, Oth{}, kt);
+    }
     FBS_TRACE_INIT
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
@@ -401,7 +446,14 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         e[1] = __builtin_amdgcn_readfirstlane(e1_next);
         e0_next = ms[2 * i + 2 < a.n ? 2 * i + 2 : a.n];   // (the last pair re-reads the body word and ignores it)
         e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
-        if (e[0] == 0 && e[1] == 0) continue;               // the bundle is zero (uniform over the workgroup)
+        const uint32_t i_next = i + 1 < n_pairs ? i + 1 : i;   // (the last step asks for its own row again: in bounds, unused)
+        if (e[0] == 0 && e[1] == 0) {                       // the bundle is zero (uniform over the workgroup)
+            if constexpr (PAIRS_PREFETCH) {     // (the words asked for ahead were this step's)
+                request_at(i_next, Pair0{}, Own{}, ko);
+                request_at(i_next, Pair0{}, Oth{}, kt);
+            }
+            continue;
+        }
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
         FBS_TRACE(0)
 
@@ -414,28 +466,17 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
             A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));   // psi^(x + N) = -psi^x
         }
         // row (jj, comp NL + lv) of step i: its own column (this component's products) and the partner's
-        const KeyRows keys(a.bsk_hat + (size_t)i * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N);   // (buffer loads: fbs_blind_rotate.hpp)
-        // (the key words of one register pair (2j, 2j + 1): three samples x NL rows, of the own or of the partner's column)
-        auto request = [&](auto jc, auto partner, double2 (&k)[3][NL]) {
-            constexpr int j = decltype(jc)::value;
-            const uint32_t col = decltype(partner)::value ? comp ^ 1u : comp;
-#pragma unroll
-            for (int jj = 0; jj < 3; jj++)
-#pragma unroll
-                for (int lv = 0; lv < NL; lv++)
-                    k[jj][lv] = keys.load(t16 + (uint32_t)(j * LANES * 16), ((uint32_t)(jj * (int)rows + lv) * 2u + col) * (uint32_t)(N * 8));
-        };
-        using Own = std::false_type;
-        using Oth = std::true_type;
+        auto request = [&](auto jc, auto partner, double2 (&k)[3][NL]) { request_at(i, jc, partner, k); };
         // Pair 0's words are requested here, ahead of the transforms; pair j + 1's when pair j has been used up.  Measured against
         // holding more through the transforms (NL = 1: all own words, 3.09 ms per 256 bootstraps against 2.89; NL = 2: two pairs,
         // 17.7 against 17.1 ms per 1024): what counts is that nothing is spilled.
         // (With the buffer loads' spare registers -- 196 at NL = 2 -- a second set of key words fits: pair j + 1 requested BEFORE pair j is
         // consumed.  Measured, same box, twice each: NL = 1 2.76-2.79 against 2.79-2.85 ms per 256 bootstraps, NL = 2 16.72-16.74
         // against 16.55 ms per 1024 -- within the noise one way, 1 % the other: not adopted.)
-        double2 ko[3][NL], kt[3][NL];
-        request(std::integral_constant<int, 0>{}, Own{}, ko);
-        request(std::integral_constant<int, 0>{}, Oth{}, kt);
+        if constexpr (!PAIRS_PREFETCH) {
+            request(Pair0{}, Own{}, ko);
+            request(Pair0{}, Oth{}, kt);
+        }
 
         // ---- ACC_c itself, rounded to the closest multiple of q / B^NL; the two cross stages; re-deal; private transforms ---------
         double x[NL][E];
@@ -478,29 +519,47 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         FBS_TRACE(3)
 
         // ---- the monomial factors ----------------------------------------------------------------------------------------
-        // psi^(e o_lane) omega^s, s = 0 .. 3.  (Scalars, one set per exponent, on purpose: as one array indexed by the exponent's
-        // loop variable the compiler turns the selections below into indexed loads from a copy it keeps in scratch memory --
-        // 24 loads per step in the place of register selects, 3.4 ms per bootstrap instead of 2.9.)
+        // zeta_m^e = psi^(e o_lane) omega^(e k_m), k_m = r1 + 2 r0 + 4 r2 for register m = (r2 r1 r0); omega^(t + 4) = -omega^t.
+        // NL = 1: omega^e is WAVE-UNIFORM -- it and its second and third power are picked by SCALAR instructions among 1, omega,
+        // omega^2, omega^3 and their negatives and multiplied into psi^(e o_lane) once each (three exact products per exponent);
+        // what is left per register is a compile-time choice among the four and, for k_m >= 4, the sign omega^(4 e) = (-1)^e as
+        // one bit operation.  (Round 4; before, the products were by omega, omega^2, omega^3 and the choice per register was 35
+        // v_cndmask behind scalar bit tests: 1 548 -> 1 510 instructions per wave and step, 235 -> 159 registers; with the key words
+        // asked for a step ahead, 2.62 / 2.84 -> 2.48 / 2.67 ms per launch of 64 / 256 bootstraps on one box.)
+        // NL = 2 keeps the form it had: the wave-uniform factor omega^(e k_m) is picked by scalar instructions PER REGISTER and
+        // multiplied in (24 exact products per step where the form above has 9).  The form above was measured there too, same box:
+        // 2 424 -> 2 332 instructions, 196 -> 212 registers, and 16.51 -> 16.81 ms per 1 024 bootstraps, 4.09 -> 4.17 per 64 -- that
+        // kernel waits for its key rows (below), not for the issue port.
+        // (The two forms are written out separately on purpose: how the selections are spelled decides whether the compiler keeps
+        // them in registers -- a nested-conditional spelling of the NL = 1 form came back with a table in LDS and 32 bytes of scratch.)
         struct Powers {
-            double s0, s1, s2, s3;
+            double s[4];
         };
-        auto powers = [&](double base) {
-            if constexpr (NL == 1) return Powers{base, fp_mulmod(base, om1), fp_mulmod(base, om2), fp_mulmod(base, om3)};
-            else return Powers{base, 0.0, 0.0, 0.0};
-        };
-        const Powers V0 = powers(A[0]), V1 = powers(A[1]), V2 = powers(A[2]);
-        // zeta^e - 1 for register m: k_m = r1 + 2 r0 + 4 r2 with m = 4 r2 + 2 r1 + r0; omega^(t + 4) = -omega^t
-        // (NL = 2 has no registers for the twelve powers: there the WAVE-UNIFORM factor omega^(e k_m) is picked by scalar
-        // instructions and multiplied in -- 7 FP64 instructions per factor where the selects take 8 half-rate ones)
-        auto mono = [&](const Powers &V, uint32_t ej, int m) {
-            const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
-            const uint32_t tt = (ej * km) & 7u;                                      // wave-uniform
+        auto powers = [&](double base, uint32_t ej) {
+            Powers V;
+            V.s[0] = base;
             if constexpr (NL == 1) {
-                const double v = (tt & 2u) ? ((tt & 1u) ? V.s3 : V.s2) : ((tt & 1u) ? V.s1 : V.s0);
-                return ((tt & 4u) ? -v : v) - 1.0;
+#pragma unroll
+                for (int q = 1; q < 4; q++) {
+                    const uint32_t idx = ej * (uint32_t)q, r = idx & 3u;                 // wave-uniform
+                    const double v = r == 3u ? om3 : r == 2u ? om2 : r == 1u ? om1 : 1.0;
+                    V.s[q] = fp_mulmod(base, (idx & 4u) ? -v : v);
+                }
+            }
+            return V;
+        };
+        const Powers V0 = powers(A[0], e[0]), V1 = powers(A[1], e[1]), V2 = powers(A[2], e[2]);
+        auto mono = [&](const Powers &V, uint32_t ej, int m) {
+            if constexpr (NL == 1) {
+                const int km = ((m >> 1) & 1) | ((m & 1) << 1) | (m & 4);
+                const double v = V.s[km & 3];
+                if (!(km & 4)) return v - 1.0;
+                return __hiloint2double(__double2hiint(v) ^ (int)(ej << 31), __double2loint(v)) - 1.0;   // times (-1)^e
             } else {
+                const uint32_t km = (uint32_t)(((m >> 1) & 1) | ((m & 1) << 1) | (m & 4));
+                const uint32_t tt = (ej * km) & 7u;                                      // wave-uniform
                 const double om = (tt & 2u) ? ((tt & 1u) ? om3 : om2) : ((tt & 1u) ? om1 : 1.0);
-                return fp_mulmod(V.s0, (tt & 4u) ? -om : om) - 1.0;    // |.| < 0.75 q + 1: the products below stay exact
+                return fp_mulmod(V.s[0], (tt & 4u) ? -om : om) - 1.0;    // |.| < 0.75 q + 1: the products below stay exact
             }
         };
         // bundle words of a register (lazy sums of three exact products, < 2.4 q) times the digits' evaluations: |x| < 2^49.3,
@@ -548,6 +607,12 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         FBS_TRACE(5)
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
+        if constexpr (PAIRS_PREFETCH) {
+            // the NEXT step's first register pair: the key rows of a step do not depend on its data, so they stream in behind the
+            // inverse transform (k_blind_rotate_cu_k2, fbs_blind_rotate_k2.hip, has the measurements of this order)
+            request_at(i_next, Pair0{}, Own{}, ko);
+            request_at(i_next, Pair0{}, Oth{}, kt);
+        }
         // (no favour() in this kernel.  Measured with it: NL = 1 2.92 -> 2.96-3.05 ms per 256 bootstraps, NL = 2 4.5 -> 4.5 / 7.1 ms.
         // The trace shows the products phase far from issue-bound -- the wave that leads it takes 3.0 M cycles for 1.6 M cycles of
         // instructions (NL = 2), the one that follows 5.4 M, whichever way the lead is given.  Its arithmetic alone runs at the

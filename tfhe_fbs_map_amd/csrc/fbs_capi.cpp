@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "fbs_internal.hpp"
+#include "fbs_plan.hpp"
 
 using namespace fbs;
 
@@ -195,9 +196,10 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     if (!params || !out) return set_error(nullptr, FBS_E_INVALID, "null argument");
     *out = nullptr;
     std::unique_ptr<fbs_ctx> ctx(new fbs_ctx);
-    ctx->p = *params;
-    ctx->seed = seed;
-    ctx->rkey = seed32 ? rand_key_derive(seed32, *params) : rand_key_from_seed64(seed);
+    // everything that is arithmetic on the parameter set (ranges, derived sizes, Delta, gadget factors, the random key): host code
+    // with no device in it (fbs_host.cpp: the sanitizer harness of tests/c/ runs the same function)
+    int rc = host_ctx_init(ctx.get(), params, seed, seed32);
+    if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
     ctx->device = device;
     // A/B switches of the launchers, settable per context with fbs_ctx_tune; the environment gives the defaults of a process
     ctx->tune.ks_gemm_min = env_knob("FBS_KS_GEMM_MIN", ctx->tune.ks_gemm_min);
@@ -210,27 +212,8 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     ctx->tune.br_cu_max_per_cu = env_knob("FBS_BR_CU_MAX_PER_CU", ctx->tune.br_cu_max_per_cu);
     ctx->tune.br_cu_lean = env_knob("FBS_BR_CU_LEAN", ctx->tune.br_cu_lean);
     ctx->tune.br_k2_shape = env_knob("FBS_BR_K2_SHAPE", ctx->tune.br_k2_shape);
-    const fbs_params &p = ctx->p;
-    if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
-        p.t_ksk > 64)
-        return set_error(nullptr, FBS_E_INVALID, "parameter out of range");
-    if (p.bsk_group > 2 || (p.bsk_group == 2 && (p.n & 1)))
-        return set_error(nullptr, FBS_E_INVALID, "bsk_group is 0, 1 or 2, and 2 needs an even n");
-    ctx->N = 1u << p.log_n_poly;
-    ctx->D = p.k * ctx->N;
-    ctx->rows = (p.k + 1) * p.l_bsk;
-    ctx->group = p.bsk_group == 2 ? 2 : 1;
-    ctx->n_ggsw = ctx->group == 2 ? (size_t)p.n / 2 * 3 : p.n;
-    ctx->ksk_stride = ((p.n + 1 + 255) / 256) * 256;
-    int rc = dev_supported(ctx.get());
+    rc = dev_supported(ctx.get());   // (is there a kernel instantiation for this shape?)
     if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
-    ctx->delta_half = (uint64_t)(((unsigned __int128)FQ + 2ull * p.p_msg) / (4ull * p.p_msg));
-    auto round_div = [](uint32_t e) {
-        unsigned __int128 d = (unsigned __int128)1 << e;
-        return (uint64_t)(((unsigned __int128)FQ + d / 2) / d);
-    };
-    for (uint32_t lv = 0; lv < p.l_bsk; lv++) ctx->g[lv] = round_div(p.beta_bsk * (lv + 1));
-    for (uint32_t v = 0; v < p.t_ksk; v++) ctx->h[v] = round_div(p.gamma_ksk * (v + 1));
 
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -714,206 +697,62 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
     *out = nullptr;
     if (flags & ~(uint32_t)FBS_LOAD_FUSE_TABLES) return set_error(ctx, FBS_E_INVALID, "unknown load flag");
     if ((flags & FBS_LOAD_FUSE_TABLES) && ctx->p.k != 1) return set_error(ctx, FBS_E_INVALID, "shared rotations (FBS_LOAD_FUSE_TABLES) are built for k = 1");
-    // counts are checked BEFORE anything is sized by them (wire ids are 32-bit: n_inputs + n_instr must not wrap)
-    if ((uint64_t)d->n_inputs + d->n_instr > FBS_MAX_WIRES || d->n_terms > FBS_MAX_TERMS || d->n_outputs > FBS_MAX_WIRES)
-        return set_error(ctx, FBS_E_INVALID, "program too large: n_inputs + n_instr and n_outputs are bounded by FBS_MAX_WIRES, n_terms by FBS_MAX_TERMS");
-    if ((d->n_instr && (!d->kind || !d->arg0 || !d->arg1 || !d->const_coef)) || (d->n_terms && (!d->term_coef || !d->term_src)) ||
-        (d->n_outputs && !d->out_wire))
-        return set_error(ctx, FBS_E_INVALID, "null array in the program description");
+    // the schedule: levels, wire slots by liveness, stage tables -- host arithmetic with no device in it (fbs_plan.cpp; the same
+    // function runs under the sanitizers in tests/c/host_harness.cpp)
+    ProgramPlan plan;
+    std::string why;
+    const bool fuse = (flags & FBS_LOAD_FUSE_TABLES) != 0;
+    if (plan_program(d, tv ? tv->n_tables : 0u, fuse && tv ? tv->fusable.data() : nullptr, &plan, &why) != FBS_OK)
+        return set_error(ctx, FBS_E_INVALID, why);
     std::unique_ptr<fbs_prog, void (*)(fbs_prog *)> prog(new fbs_prog, fbs_program_destroy);
-    prog->fused = (flags & FBS_LOAD_FUSE_TABLES) != 0;
+    prog->fused = fuse;
     prog->ctx = ctx;
     prog->tv = tv;
     prog->n_inputs = d->n_inputs;
     prog->n_instr = d->n_instr;
     prog->n_outputs = d->n_outputs;
-    prog->n_wires = d->n_inputs + d->n_instr;
-    const uint32_t n_wires = prog->n_wires;
-
-    // levels: inputs 0, LinearProd = max over sources, Bootstrap = source + 1
-    std::vector<uint32_t> level(n_wires, 0), sub(n_wires, 0);
-    std::vector<uint8_t> is_lin(n_wires, 0);
-    for (uint32_t i = 0; i < d->n_instr; i++) {
-        const uint32_t w = d->n_inputs + i;
-        if (d->kind[i] == 0) {
-            is_lin[w] = 1;
-            if ((uint64_t)d->arg0[i] + d->arg1[i] > d->n_terms) return set_error(ctx, FBS_E_INVALID, "term range out of bounds");
-            uint32_t lv = 0, sb = 0;
-            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
-                const uint32_t s = d->term_src[t];
-                if (s >= w) return set_error(ctx, FBS_E_INVALID, "instruction " + std::to_string(i) + " reads a later wire");
-                lv = std::max(lv, level[s]);
-            }
-            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
-                const uint32_t s = d->term_src[t];
-                if (is_lin[s] && level[s] == lv) sb = std::max(sb, sub[s] + 1);
-            }
-            level[w] = lv;
-            sub[w] = sb;
-        } else if (d->kind[i] == 1) {
-            if (d->arg0[i] >= w) return set_error(ctx, FBS_E_INVALID, "instruction " + std::to_string(i) + " reads a later wire");
-            if (!tv || d->arg1[i] >= tv->n_tables) return set_error(ctx, FBS_E_INVALID, "table id out of range");
-            level[w] = level[d->arg0[i]] + 1;
-            prog->depth = std::max(prog->depth, level[w]);
-            prog->n_bootstrap++;
-        } else {
-            return set_error(ctx, FBS_E_INVALID, "unknown instruction kind");
-        }
-    }
-    for (uint32_t o = 0; o < d->n_outputs; o++)
-        if (d->out_wire[o] >= (int64_t)n_wires) return set_error(ctx, FBS_E_INVALID, "output wire out of range");
-
-    const uint32_t depth = prog->depth;
-    // ---- stages in execution order: for each level its lincomb sub-stages, then its bootstraps ----------------
-    std::vector<uint32_t> n_sub(depth + 1, 0);
-    for (uint32_t w = d->n_inputs; w < n_wires; w++)
-        if (is_lin[w]) n_sub[level[w]] = std::max(n_sub[level[w]], sub[w] + 1);
-    std::vector<uint32_t> lin_time0(depth + 1, 0), boot_time(depth, 0);
-    uint32_t n_stages = 0;
-    for (uint32_t L = 0; L <= depth; L++) {
-        lin_time0[L] = n_stages;
-        n_stages += n_sub[L];
-        if (L < depth) boot_time[L] = n_stages++;
-    }
-    auto def_time = [&](uint32_t w) -> int64_t {
-        if (w < d->n_inputs) return -1;
-        return is_lin[w] ? (int64_t)lin_time0[level[w]] + sub[w] : (int64_t)boot_time[level[w] - 1];
-    };
-    // ---- liveness: a wire keeps its slot until the stage of its last reader has run (outputs: for ever) ---------
-    const int64_t FOREVER = (int64_t)n_stages + 1;
-    std::vector<int64_t> last(n_wires);
-    for (uint32_t w = 0; w < n_wires; w++) last[w] = def_time(w);
-    for (uint32_t i = 0; i < d->n_instr; i++) {
-        const uint32_t w = d->n_inputs + i;
-        const int64_t t = def_time(w);
-        if (d->kind[i] == 0) {
-            for (uint32_t k = d->arg0[i]; k < d->arg0[i] + d->arg1[i]; k++) last[d->term_src[k]] = std::max(last[d->term_src[k]], t);
-        } else {
-            last[d->arg0[i]] = std::max(last[d->arg0[i]], t);
-        }
-    }
-    for (uint32_t o = 0; o < d->n_outputs; o++)
-        if (d->out_wire[o] >= 0) last[d->out_wire[o]] = FOREVER;
-    std::vector<std::vector<uint32_t>> born(n_stages + 1), dies(n_stages + 1);   // index = time + 1
-    for (uint32_t w = 0; w < n_wires; w++) {
-        born[def_time(w) + 1].push_back(w);
-        if (last[w] != FOREVER) dies[last[w] + 1].push_back(w);
-    }
-    std::vector<uint32_t> slot(n_wires, 0), free_slots;   // free_slots: min-heap, lowest slot first (compact buffer)
-    auto cmp = std::greater<uint32_t>();
-    uint32_t n_slots = 0;
-    for (uint32_t t = 0; t <= n_stages; t++) {
-        for (uint32_t w : born[t]) {
-            if (free_slots.empty()) {
-                slot[w] = n_slots++;
-            } else {
-                std::pop_heap(free_slots.begin(), free_slots.end(), cmp);
-                slot[w] = free_slots.back();
-                free_slots.pop_back();
-            }
-        }
-        // freed only now: a slot is never rewritten by the stage that reads it last
-        for (uint32_t w : dies[t]) {
-            free_slots.push_back(slot[w]);
-            std::push_heap(free_slots.begin(), free_slots.end(), cmp);
-        }
-    }
-    prog->n_slots = std::max(1u, n_slots);
-    prog->in_slot.assign(slot.begin(), slot.begin() + d->n_inputs);
-    prog->out_slot.resize(d->n_outputs);
-    for (uint32_t o = 0; o < d->n_outputs; o++) prog->out_slot[o] = d->out_wire[o] >= 0 ? (int64_t)slot[d->out_wire[o]] : d->out_wire[o];
-
-    // ---- stage tables (wire slots, not wire ids) ---------------------------------------------------------------
-    prog->lin.resize(depth + 1);
-    prog->boot.resize(depth);
-    struct LinHost {
-        std::vector<uint32_t> dst, off{0}, srcs;
-        std::vector<uint64_t> coefs, consts;
-    };
-    std::vector<std::vector<LinHost>> lh(depth + 1);
-    struct Gate {
-        uint32_t src, dst, tab;
-    };
-    std::vector<std::vector<Gate>> bh(depth);
-    for (uint32_t i = 0; i < d->n_instr; i++) {
-        const uint32_t w = d->n_inputs + i;
-        if (d->kind[i] == 0) {
-            auto &stages = lh[level[w]];
-            if (stages.size() <= sub[w]) stages.resize(sub[w] + 1);
-            LinHost &h = stages[sub[w]];
-            h.dst.push_back(slot[w]);
-            for (uint32_t t = d->arg0[i]; t < d->arg0[i] + d->arg1[i]; t++) {
-                h.srcs.push_back(slot[d->term_src[t]]);
-                h.coefs.push_back(coef_bits(d->term_coef[t]));
-            }
-            h.off.push_back((uint32_t)h.srcs.size());
-            h.consts.push_back(fq_mul(fq_from_i64(d->const_coef[i]), 2 * ctx->delta_half));
-        } else {
-            bh[level[w] - 1].push_back({d->arg0[i], slot[w], d->arg1[i]});
-        }
-    }
-    for (uint32_t L = 0; L <= depth; L++) {
-        for (LinHost &h : lh[L]) {
+    prog->n_wires = plan.n_wires;
+    prog->n_slots = plan.n_slots;
+    prog->depth = plan.depth;
+    prog->max_width = plan.max_width;
+    prog->max_sources = plan.max_sources;
+    prog->max_shared = plan.max_shared;
+    prog->n_bootstrap = plan.n_bootstrap;
+    prog->n_keyswitch = plan.n_keyswitch;
+    prog->n_rotations = plan.n_rotations;
+    prog->in_slot = plan.in_slot;
+    prog->out_slot = plan.out_slot;
+    // ---- upload the stage tables (coefficients and constants mapped into the field) ----------------------------------
+    prog->lin.resize(plan.depth + 1);
+    prog->boot.resize(plan.depth);
+    for (uint32_t L = 0; L <= plan.depth; L++) {
+        for (const LinPlan &h : plan.lin[L]) {
             LincombStage st;
             st.n_out = (uint32_t)h.dst.size();
+            std::vector<uint64_t> coefs(h.coefs.size()), consts(h.consts.size());
+            for (size_t i = 0; i < coefs.size(); i++) coefs[i] = coef_bits(h.coefs[i]);
+            for (size_t i = 0; i < consts.size(); i++) consts[i] = fq_mul(fq_from_i64(h.consts[i]), 2 * ctx->delta_half);
             if (st.n_out &&
                 ((rc = to_device(ctx, prog.get(), h.dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), h.off, &st.d_term_off)) ||
-                 (rc = to_device(ctx, prog.get(), h.srcs, &st.d_srcs)) || (rc = to_device(ctx, prog.get(), h.coefs, &st.d_coefs)) ||
-                 (rc = to_device(ctx, prog.get(), h.consts, &st.d_consts))))
+                 (rc = to_device(ctx, prog.get(), h.srcs, &st.d_srcs)) || (rc = to_device(ctx, prog.get(), coefs, &st.d_coefs)) ||
+                 (rc = to_device(ctx, prog.get(), consts, &st.d_consts))))
                 return rc;
-            prog->lin[L].push_back(st);   // kept even when empty: stage times above count every sub-stage
+            prog->lin[L].push_back(st);   // kept even when empty: the plan's stage times count every sub-stage
         }
     }
-    for (uint32_t L = 0; L < depth; L++) {
-        std::vector<Gate> &gates = bh[L];
-        std::stable_sort(gates.begin(), gates.end(), [](const Gate &x, const Gate &y) { return x.src < y.src; });
+    for (uint32_t L = 0; L < plan.depth; L++) {
+        const BootPlan &h = plan.boot[L];
         BootStage st;
-        std::vector<uint32_t> src_slot, dst, tab, x_row, x_table, x_dst, x_gate;
-        for (size_t g = 0; g < gates.size();) {
-            size_t e = g;
-            while (e < gates.size() && gates[e].src == gates[g].src) e++;
-            src_slot.push_back(slot[gates[g].src]);
-            const uint32_t u = (uint32_t)src_slot.size() - 1;
-            // fused: the tables of this source that k_multi_extract can serve share one rotation of TV_0, if there are
-            // at least two of them; the others keep a rotation of their own
-            size_t n_fusable = 0;
-            if (prog->fused)
-                for (size_t i = g; i < e; i++) n_fusable += tv->fusable[gates[i].tab];
-            const bool share = n_fusable >= 2;
-            const uint32_t shared_at = (uint32_t)dst.size();
-            if (share) {
-                st.source_of.push_back(u);
-                dst.push_back(0x80000000u | st.n_shared);
-                tab.push_back(tv->n_tables);
-            }
-            for (size_t i = g; i < e; i++) {
-                if (share && tv->fusable[gates[i].tab]) {
-                    x_row.push_back(st.n_shared);
-                    x_gate.push_back(shared_at);
-                    x_table.push_back(gates[i].tab);
-                    x_dst.push_back(gates[i].dst);
-                } else {
-                    st.source_of.push_back(u);
-                    dst.push_back(gates[i].dst);
-                    tab.push_back(gates[i].tab);
-                }
-            }
-            if (share) st.n_shared++;
-            g = e;
-        }
-        st.n_gates = (uint32_t)dst.size();
-        st.n_extract = (uint32_t)x_row.size();
-        st.n_sources = (uint32_t)src_slot.size();
-        prog->max_width = std::max(prog->max_width, st.n_gates);
-        prog->max_sources = std::max(prog->max_sources, st.n_sources);
-        prog->max_shared = std::max(prog->max_shared, st.n_shared);
-        prog->n_keyswitch += st.n_sources;
-        prog->n_rotations += st.n_gates;
-        if ((rc = to_device(ctx, prog.get(), src_slot, &st.d_src_slot)) || (rc = to_device(ctx, prog.get(), st.source_of, &st.d_source_of)) ||
-            (rc = to_device(ctx, prog.get(), dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), tab, &st.d_table)))
+        st.n_gates = (uint32_t)h.dst.size();
+        st.n_sources = (uint32_t)h.src_slot.size();
+        st.n_shared = h.n_shared;
+        st.n_extract = (uint32_t)h.x_row.size();
+        st.source_of = h.source_of;
+        if ((rc = to_device(ctx, prog.get(), h.src_slot, &st.d_src_slot)) || (rc = to_device(ctx, prog.get(), h.source_of, &st.d_source_of)) ||
+            (rc = to_device(ctx, prog.get(), h.dst, &st.d_dst)) || (rc = to_device(ctx, prog.get(), h.table, &st.d_table)))
             return rc;
-        if (st.n_extract && ((rc = to_device(ctx, prog.get(), x_row, &st.d_x_row)) || (rc = to_device(ctx, prog.get(), x_table, &st.d_x_table)) ||
-                             (rc = to_device(ctx, prog.get(), x_dst, &st.d_x_dst)) || (rc = to_device(ctx, prog.get(), x_gate, &st.d_x_gate))))
+        if (st.n_extract && ((rc = to_device(ctx, prog.get(), h.x_row, &st.d_x_row)) || (rc = to_device(ctx, prog.get(), h.x_table, &st.d_x_table)) ||
+                             (rc = to_device(ctx, prog.get(), h.x_dst, &st.d_x_dst)) || (rc = to_device(ctx, prog.get(), h.x_gate, &st.d_x_gate))))
             return rc;
         prog->boot[L] = std::move(st);
     }

@@ -124,6 +124,34 @@ static void parallel_for(size_t n, const std::function<void(size_t, size_t)> &bo
 // ---------------------------------------------------------------------------------------------
 // keys
 // ---------------------------------------------------------------------------------------------
+// What a context derives from its parameter set before any device is involved: range checks, sizes, Delta = 2 round(q / 4p),
+// the gadget factors g_l = round(q / 2^(beta (l+1))), h_v = round(q / 2^(gamma (v+1))), and the key all randomness is expanded from.
+int host_ctx_init(fbs_ctx *ctx, const fbs_params *params, uint64_t seed, const uint8_t *seed32) {
+    ctx->p = *params;
+    ctx->seed = seed;
+    ctx->rkey = seed32 ? rand_key_derive(seed32, *params) : rand_key_from_seed64(seed);
+    const fbs_params &p = ctx->p;
+    if (p.log_n_poly < 2 || p.log_n_poly > 14 || p.k < 1 || p.k > 4 || p.p_msg < 1 || p.p_msg > 4096 || p.l_bsk > 16 ||
+        p.t_ksk > 64)
+        return set_error(ctx, FBS_E_INVALID, "parameter out of range");
+    if (p.bsk_group > 2 || (p.bsk_group == 2 && (p.n & 1)))
+        return set_error(ctx, FBS_E_INVALID, "bsk_group is 0, 1 or 2, and 2 needs an even n");
+    ctx->N = 1u << p.log_n_poly;
+    ctx->D = p.k * ctx->N;
+    ctx->rows = (p.k + 1) * p.l_bsk;
+    ctx->group = p.bsk_group == 2 ? 2 : 1;
+    ctx->n_ggsw = ctx->group == 2 ? (size_t)p.n / 2 * 3 : p.n;
+    ctx->ksk_stride = ((p.n + 1 + 255) / 256) * 256;
+    ctx->delta_half = (uint64_t)(((unsigned __int128)FQ + 2ull * p.p_msg) / (4ull * p.p_msg));
+    auto round_div = [](uint32_t e) {
+        unsigned __int128 d = (unsigned __int128)1 << e;
+        return (uint64_t)(((unsigned __int128)FQ + d / 2) / d);
+    };
+    for (uint32_t lv = 0; lv < p.l_bsk; lv++) ctx->g[lv] = round_div(p.beta_bsk * (lv + 1));
+    for (uint32_t v = 0; v < p.t_ksk; v++) ctx->h[v] = round_div(p.gamma_ksk * (v + 1));
+    return FBS_OK;
+}
+
 void host_keygen(fbs_ctx *ctx) {
     const fbs_params &p = ctx->p;
     const uint32_t N = ctx->N, D = ctx->D, n = p.n, k = p.k, l = p.l_bsk, t = p.t_ksk, rows = ctx->rows;

@@ -216,6 +216,7 @@ int translate_exception(Report &&report) noexcept {
     }
 
 // host side (fbs_host.cpp)
+int host_ctx_init(fbs_ctx *ctx, const fbs_params *params, uint64_t seed, const uint8_t *seed32);   // errors: text in ctx->err
 void host_keygen(fbs_ctx *ctx);
 void host_encrypt(const fbs_ctx *ctx, const int64_t *msgs, size_t count, uint64_t nonce0, uint64_t *cts);
 void host_decrypt(const fbs_ctx *ctx, const uint64_t *cts, size_t count, int64_t *msgs);

@@ -1,4 +1,4 @@
-"""The k = 2 latency shape of the library named by $FBS_LIB (kernel-variant experiments, tools/build_k2_variants.sh): a spot check
+"""The k = 2 latency shape of the library named by $FBS_LIB (kernel-variant experiments, tools/build_variants.sh): a spot check
 against the oracle at toy n, then per-launch times at the shipped 128-bit set.   python3 tools/k2_latency.py [shape = 12] [steps = 6] [sizes ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
