@@ -16,7 +16,9 @@
 // so the order in which the three additions land does not matter -- and after a second barrier each wave reads its total back
 // and inverts it.  Two workgroup barriers per step, none inside the transforms.
 // (Round 4, measured and not adopted: the next step's first register pair of key words requested behind the read-back, as the
-// twelve-wave shape below does -- 168 registers with 160 bytes spilled instead of 12: 7.60 against 7.21 ms per 1 024.)
+// twelve-wave shape below does -- 168 registers with 160 bytes spilled instead of 12: 7.60 against 7.21 ms per 1 024; and the
+// monomial factors as psi^(e o_lane) (ONE gather per exponent) times the wave-uniform psi^(e c_m) read through the scalar cache, in
+// the place of a gather from the table in LDS per register pair and exponent: 7.40 against 7.24 ms, same box, twice.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -72,15 +72,15 @@ def split_range(total, parts, r):
 #   "n2048"     k = 1, N = 2048, two key bits per step, one level, n = 714 (p = 15 at heavy norms; shared rotations):
 #               k_blind_rotate_cu_pairs<11,1> up to one per CU, k_blind_rotate_pairs<11,7,4> beyond
 #   "n2048_l2"  the same with two levels, n = 766 (p = 31, BASELINE configs[4]): k_blind_rotate_cu_pairs<11,2>, round after round
-LAUNCH_MS_P1024 = ((1, 2.91), (128, 2.92), (256, 3.14), (257, 5.46), (512, 5.53), (513, 8.21), (768, 8.21), (769, 9.29), (1024, 9.29))
+LAUNCH_MS_P1024 = ((1, 2.83), (128, 2.89), (256, 3.09), (257, 5.43), (512, 5.52), (513, 8.0), (768, 8.17), (769, 8.31), (896, 8.96), (1024, 9.30))
 ROUND_MS_P1024 = 9.20      # per further round of 1024 in a long launch (8192 bootstraps: 73.8 ms)
 LAUNCH_FAMILIES = {
     "p1024": dict(steps=630, stairs=LAUNCH_MS_P1024, round_ms=ROUND_MS_P1024, full_from=896),
-    "k2": dict(steps=367, stairs=((1, 2.06), (128, 2.11), (256, 2.36), (257, 4.34), (512, 4.43), (513, 6.37), (768, 6.37), (769, 6.79), (896, 6.89),
-                                  (1024, 7.22)), round_ms=7.22, full_from=769),
-    "n2048": dict(steps=357, stairs=((1, 2.61), (128, 2.65), (256, 2.89), (257, 5.35), (512, 5.35), (513, 7.9), (768, 8.0), (769, 9.25), (1024, 9.25)),
-                  round_ms=9.2, full_from=896),
-    "n2048_l2": dict(steps=383, stairs=((1, 4.27), (256, 4.61), (257, 8.7), (512, 8.7), (513, 13.0), (768, 13.0), (769, 16.6), (1024, 16.6)),
+    "k2": dict(steps=367, stairs=((1, 2.08), (128, 2.21), (256, 2.46), (257, 4.54), (512, 4.55), (513, 6.6), (768, 6.5), (769, 6.87), (896, 7.04),
+                                  (1024, 7.39)), round_ms=7.3, full_from=769),
+    "n2048": dict(steps=357, stairs=((1, 2.52), (128, 2.59), (256, 2.86), (257, 4.69), (512, 4.86), (513, 7.8), (768, 7.4), (769, 9.66), (1024, 9.34)),
+                  round_ms=9.0, full_from=769),
+    "n2048_l2": dict(steps=383, stairs=((1, 4.16), (128, 4.18), (256, 4.44), (257, 9.0), (512, 8.5), (513, 13.7), (768, 12.5), (769, 17.8), (1024, 16.66)),
                      round_ms=16.6, full_from=769),
 }
 
@@ -112,7 +112,7 @@ def launch_ms(count, cost=1.0, params=None):
     rounds, rest = divmod(int(count), 1024)
     if rounds and rest >= fam["full_from"]:
         rounds, rest = rounds + 1, 0
-    ms = rounds * fam["round_ms"] + (0.2 if name == "p1024" and rounds == 1 and not rest else 0.0)
+    ms = rounds * fam["round_ms"] + (0.1 if rounds == 1 and not rest else 0.0)   # (the first round of a launch: fill and drain)
     if rest:
         xs, ys = zip(*fam["stairs"])
         ms += float(np.interp(rest, xs, ys))

@@ -1,8 +1,8 @@
 #!/bin/bash
 # gpurun_out/prof_<tag>/ (tools/profile_round.sh) -> profiles/<round>/: per-set summaries + kernel-trace stats, and the PMC record
 # bench.py reads (stamped with the SHA-256 of the kernel sources as they are NOW: run right after the profile round).
-#   usage (here, after the gpurun call merged its outputs): bash tools/collect_profiles.sh r03 r03
-TAG=${1:-r03}; ROUND=${2:-r03}
+#   usage (here, after the gpurun call merged its outputs): bash tools/collect_profiles.sh r04 r04
+TAG=${1:-r04}; ROUND=${2:-r04}
 SRC=gpurun_out/prof_$TAG; DST=profiles/$ROUND
 mkdir -p $DST
 rm -f $DST/pmc_blind_rotate.json
@@ -23,6 +23,8 @@ rec p63 822 1 1024
 rec p4 638 1 1024
 rec securek2 734 2 1024
 rec p4k2 630 2 1024
+rec k2cu256 734 2 256
+rec k2cu512 734 2 512
 rec secure256 714 2 256
 rec p31cu 766 2 256
 rec lean512 630 1 512

@@ -6,8 +6,9 @@
 #         step), secure1 (one key bit per step), p31 (config 5: 128-bit set for p = 31, two key bits per step on whole CUs),
 #         p31g1 (the same with one key bit per step), p63 (N = 4096, one key bit per step), p4 (N = 1024 128-bit set),
 #         securek2 / p4k2 (GLWE dimension k = 2 at N = 1024: k_blind_rotate_pairs_k2 at the 128-bit sets for p = 15 and p = 4),
-#         secure256 / p31cu (the p = 15 and p = 31 sets at one bootstrap per CU), lean512 (bench.py --batch 512: two workgroups per CU)
-TAG=${1:-r03}; shift
+#         secure256 / p31cu (the p = 15 and p = 31 sets at one bootstrap per CU), lean512 (bench.py --batch 512: two workgroups per CU),
+#         k2cu256 / k2cu512 (the k = 2 set for p = 15 on k_blind_rotate_cu_k2: one bootstrap on the twelve waves of a workgroup, one / two rounds)
+TAG=${1:-r04}; shift
 SETS=${@:-p1024 cu256 secure p31}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TOP=gpurun_out/prof_$TAG
@@ -40,6 +41,8 @@ for S in $SETS; do
     securek2) run_set securek2 python3 tools/secure_bench.py 1024 5 15 70 k2 ;;
     p4k2)    run_set p4k2 python3 tools/secure_bench.py 1024 5 4 2 k2 ;;
     secure256) run_set secure256 python3 tools/secure_bench.py 256 8 15 70 ;;
+    k2cu256) run_set k2cu256 python3 tools/secure_bench.py 256 8 15 70 k2 ;;
+    k2cu512) run_set k2cu512 python3 tools/secure_bench.py 512 6 15 70 k2 ;;
     p31cu)   run_set p31cu python3 tools/secure_bench.py 256 6 31 325 ;;
     lean512) run_set lean512 python3 bench.py --batch 512 --steps 10 --cpu-sample 0 --no-secure ;;
   esac
