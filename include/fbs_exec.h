@@ -234,7 +234,7 @@ int fbs_program_load(fbs_ctx *ctx, const fbs_program_desc *desc, const fbs_tvset
  * differ from the unfused program's.  Into the wire slots a level of a fused program runs whole (fbs_eval, fbs_eval_dev,
  * fbs_level_bootstrap_dev over the full range without d_rows).  Across GPUs the unit dealt out is the ROTATION:
  * fbs_level_bootstrap_dev with d_rows takes any slice of the level's (rotation, sample) grid, its rows are
- * fbs_layout.row_words = 2N words -- an ordinary gate leaves its ciphertext there, a shared rotation its whole accumulator --
+ * fbs_layout.row_words = (k + 1) N words -- an ordinary gate leaves its ciphertext there, a shared rotation its whole accumulator --
  * and fbs_level_scatter_dev, given all rows of the level, files the ciphertexts and cuts every table out of the gathered
  * accumulators. */
 #define FBS_LOAD_FUSE_TABLES 1u
@@ -280,7 +280,7 @@ typedef struct fbs_layout {
     uint32_t n_keyswitch;  /* key switches in the program (<= n_bootstrap: shared sources)     */
     uint32_t n_inputs, n_outputs;
     uint32_t n_rotations;  /* blind rotations per sample (< n_bootstrap when tables share them)       */
-    uint32_t row_words;    /* words per row of the d_rows arrays below: D + 1, or 2N for a fused program       */
+    uint32_t row_words;    /* words per row of the d_rows arrays below: D + 1, or (k + 1) N for a fused program */
 } fbs_layout;
 int fbs_program_layout(const fbs_prog *prog, fbs_layout *out);
 int fbs_program_level(const fbs_prog *prog, uint32_t level, uint32_t *n_gates, uint32_t *n_sources);

@@ -18,7 +18,8 @@ from tests.helpers import load_fixture, subsample      # noqa: E402
 def main():
     name, T, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
-    k2 = len(sys.argv) > 4 and sys.argv[4] == "k2"      # GLWE dimension 2 at N = 1024: ciphertexts and rows of 2 N + 1 words
+    k2 = len(sys.argv) > 4 and sys.argv[4] in ("k2", "fused_k2")   # GLWE dimension 2 at N = 1024: ciphertexts and rows of 2 N + 1 words
+    fused = fused or (len(sys.argv) > 4 and sys.argv[4] == "fused_k2")   # ... with shared rotations: rows of 3 N words
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -41,7 +42,7 @@ def main():
     for mode, cls in (("gate", GateShardedRunner), ("sample", SampleShardedRunner)):
         runner = cls(GpuBackend(prog))
         if fused:
-            assert prog.n_rotations < prog.n_bootstrap and prog.row_words == 2 * prm.N
+            assert prog.n_rotations < prog.n_bootstrap and prog.row_words == (prm.k + 1) * prm.N
         res[mode] = runner.run(cts, T)
         res[mode + "_collectives"] = runner.collectives
         res[mode + "_fbs"] = runner.bootstraps_done

@@ -44,16 +44,17 @@ def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T, flavour):
     assert total // 2 - int(z["depth"]) <= int(z["gate_fbs"]) <= -(-total // 2) + int(z["depth"])      # rank 0 did half
 
 
-def test_two_ranks_on_a_fused_program(tmp_path):
+@pytest.mark.parametrize("flavour", ["fused", "fused_k2"])
+def test_two_ranks_on_a_fused_program(tmp_path, flavour):
     """A program loaded with FBS_LOAD_FUSE_TABLES (several tables on one blind rotation), cut across two ranks both ways.  Gate-
-    sharded, the unit dealt out is the ROTATION: rows are 2N words, a shared rotation's accumulator travels in its row, and every
-    rank cuts the tables out of the gathered accumulators.  Both layouts return the single-process (fused) ciphertexts, and rank 0
-    did about half of the rotations."""
+    sharded, the unit dealt out is the ROTATION: rows are (k + 1) N words, a shared rotation's accumulator travels in its row, and
+    every rank cuts the tables out of the gathered accumulators.  Both layouts return the single-process (fused) ciphertexts, and
+    rank 0 did about half of the rotations.  (fused_k2: the same at GLWE dimension 2.)"""
     name, T = "adder8__basic_p2", 4
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="2")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(T), out, "fused"],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name, str(T), out, flavour],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=600) == 0

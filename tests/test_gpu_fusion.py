@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import lut_oracle, tfhe_oracle as orc
-from tests.helpers import load_fixture, oracle_eval_program, subsample
+from tests.helpers import load_fixture, oracle_eval_program, subsample, toy_k2
 
 pytestmark = pytest.mark.gpu
 
@@ -29,17 +29,18 @@ def load(nat, prm, text, inputs, seed=6, fuse=True, merge=True):
     return ctx, low, tv, prog
 
 
-def params_for(toy_params, rec):
+def params_for(toy_params, rec, k=1):
     ops, _ = lut_oracle.read_fbs(rec["fbs"])
     p = max(7, max(len(op[3]) for op in ops if op[0] == "boot"))
-    return toy_params.replace(p_msg=p)
+    return toy_params.replace(p_msg=p) if k == 1 else toy_k2(p)      # k = 2: accumulator rows of 3 N words, ciphertexts of 2 N + 1
 
 
-@pytest.mark.parametrize("name", ["adder8__basic_p2", "2_input_gates__basic_p2", "half_adder__basic_p2"])
-def test_fused_program_equals_the_oracle_and_the_reference(nat, toy_params, name):
+@pytest.mark.parametrize("name,k", [("adder8__basic_p2", 1), ("2_input_gates__basic_p2", 1), ("half_adder__basic_p2", 1),
+                                    ("adder8__basic_p2", 2), ("2_input_gates__basic_p2", 2)])       # round 4: shared rotations at GLWE dimension 2
+def test_fused_program_equals_the_oracle_and_the_reference(nat, toy_params, name, k):
     T = 3
     rec = load_fixture(name)
-    prm = params_for(toy_params, rec)
+    prm = params_for(toy_params, rec, k)
     ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
     ops, outs = lut_oracle.read_fbs(rec["fbs"])
     distinct = len({op[2] for op in ops if op[0] == "boot"})
@@ -147,16 +148,17 @@ def test_tables_with_negative_values_below_the_facade(nat, toy_params):
         assert np.array_equal(ctx.decrypt(got[i]) % 14, np.array([full[x] for x in v]) % 14)
 
 
-def test_levels_of_a_fused_program_whole_or_sliced_into_rows(nat, toy_params):
+@pytest.mark.parametrize("k", [1, 2])
+def test_levels_of_a_fused_program_whole_or_sliced_into_rows(nat, toy_params, k):
     """Into the wire slots a level with shared rotations runs whole (a partial range is refused).  Into ROWS it can be cut
-    anywhere: rows are `row_words` = 2N words, a shared rotation leaves its accumulator in its row, and the scatter call cuts
+    anywhere: rows are `row_words` = (k + 1) N words, a shared rotation leaves its accumulator in its row, and the scatter call cuts
     the tables out of the gathered rows -- same ciphertexts as the whole evaluation."""
     import torch
     rec = load_fixture("adder8__basic_p2")
-    prm = params_for(toy_params, rec)
+    prm = params_for(toy_params, rec, k)
     T = 4
     ctx, low, tv, prog = load(nat, prm, rec["fbs"], rec["program_inputs"])
-    assert prog.row_words == 2 * prm.N
+    assert prog.row_words == (k + 1) * prm.N
     ins, _ = subsample(rec, T)
     cts = ctx.encrypt(np.stack([ins[n] for n in low["input_names"]]), nonce0=9)
     ref = prog.eval(cts, T)

@@ -275,7 +275,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
     if (!live) return;
-    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+    if (uint64_t *raw = gate_acc(a.gv, f, 2 * N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
 #pragma unroll
         for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
         return;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
     }
 
     if (!live) return;
-    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+    if (uint64_t *raw = gate_acc(a.gv, f, 2 * N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
 #pragma unroll
         for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
         return;
@@ -692,7 +692,6 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
     if (p.k == 2) {   // GLWE dimension 2 (N = 1024, two key bits per step, one level: dev_supported admits nothing else)
-        if (gv.acc_rows || gv.row_words) return set_error(ctx, FBS_E_INVALID, "shared rotations are built for k = 1");
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
         // a launch longer than a round of four-bootstrap workgroups whose last round would be (far) from full: whole rounds first,
         // the rest as a launch of its own in the twelve-wave shape (1 124 = 1 024 + 100: 7.3 + 2.1 ms against two rounds' 14.5)

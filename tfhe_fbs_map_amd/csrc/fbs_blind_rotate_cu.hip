@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
 
     // ---- sample extraction of coefficient 0, plus the table's constant -----------------------------
     if (!live) return;
-    if (uint64_t *raw = gate_acc(a.gv, f, N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+    if (uint64_t *raw = gate_acc(a.gv, f, 2 * N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
 #pragma unroll
         for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
         return;
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     FBS_TRACE_FLUSH
 
     if (!live) return;
-    if (uint64_t *raw = gate_acc(a.gv, f, N)) {
+    if (uint64_t *raw = gate_acc(a.gv, f, 2 * N)) {
 #pragma unroll
         for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
         return;

@@ -184,6 +184,11 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 
     // ---- sample extraction of coefficient 0 (two mask polynomials, the body), plus the table's constant -----------------
     if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, K1 * N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
     uint64_t *out = gate_out(a.gv, f, a.ct_words);
     if (comp < 2u) {
 #pragma unroll
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 //      points of those components -- plain stores into the receiver's two slots (barrier 2); no atomics: a wave has exactly
 //      two senders
 //   -> sum, private inverse transform, re-deal back (barrier 3), joining stages, accumulate.
-// Three workgroup barriers per step, as the k = 1 shape; 783 vector instructions per wave and step, 166 registers, nothing spilled.
+// Three workgroup barriers per step, as the k = 1 shape; 792 vector instructions per wave and step, 168 registers (eight dwords of
+// loop-invariant twiddles are kept in scratch and re-read once per step).
 // THE KEY ROWS OF A STEP DO NOT DEPEND ON ITS DATA.  One workgroup per CU pulls a step's whole row out of L2 by itself (27
 // polynomials, 221 KB; a CU streams ~100 GB/s from L2: 2.2 us of a 6 us step), so when the words are asked for decides how much of
 // that is waited for.  Measured at n = 734, per launch of 64 / 256 bootstraps (tools/k2_latency.py, one box):
@@ -425,6 +431,11 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
 
     // ---- sample extraction of coefficient 0 (two mask polynomials, the body), plus the table's constant -----------------
     if (!live) return;
+    if (uint64_t *raw = gate_acc(a.gv, f, K1 * N)) {   // a rotation of TV_0 that several tables share: the whole accumulator
+#pragma unroll
+        for (int m = 0; m < E; m++) raw[comp * N + t + (uint32_t)LANES * m] = fp_to_u64(fp_canon(acc[m]));
+        return;
+    }
     uint64_t *out = gate_out(a.gv, f, a.ct_words);
     if (comp < 2u) {
 #pragma unroll

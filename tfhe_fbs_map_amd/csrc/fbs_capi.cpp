@@ -114,7 +114,7 @@ static int ensure_acc(fbs_ctx *ctx, size_t rows) {
     if (ctx->d_acc) (void)hipFree(ctx->d_acc);
     ctx->d_acc = nullptr;
     ctx->acc_capacity = 0;
-    FBS_HIP(ctx, hipMalloc(&ctx->d_acc, rows * 2 * (size_t)ctx->N * 8));
+    FBS_HIP(ctx, hipMalloc(&ctx->d_acc, rows * (size_t)(ctx->p.k + 1) * ctx->N * 8));   // a row = a whole GLWE accumulator
     ctx->acc_capacity = rows;
     return FBS_OK;
 }
@@ -696,7 +696,6 @@ int fbs_program_load_ex(fbs_ctx *ctx, const fbs_program_desc *d, const fbs_tvset
     if (!d || !out) return set_error(ctx, FBS_E_INVALID, "null argument");
     *out = nullptr;
     if (flags & ~(uint32_t)FBS_LOAD_FUSE_TABLES) return set_error(ctx, FBS_E_INVALID, "unknown load flag");
-    if ((flags & FBS_LOAD_FUSE_TABLES) && ctx->p.k != 1) return set_error(ctx, FBS_E_INVALID, "shared rotations (FBS_LOAD_FUSE_TABLES) are built for k = 1");
     // the schedule: levels, wire slots by liveness, stage tables -- host arithmetic with no device in it (fbs_plan.cpp; the same
     // function runs under the sanitizers in tests/c/host_harness.cpp)
     ProgramPlan plan;
@@ -785,7 +784,7 @@ int fbs_program_layout(const fbs_prog *prog, fbs_layout *out) try {
     out->n_bootstrap = prog->n_bootstrap;
     out->n_keyswitch = prog->n_keyswitch;
     out->n_rotations = prog->n_rotations;
-    out->row_words = prog->fused ? 2 * prog->ctx->N : prog->ctx->D + 1;
+    out->row_words = prog->fused ? (prog->ctx->p.k + 1) * prog->ctx->N : prog->ctx->D + 1;
     out->n_inputs = prog->n_inputs;
     out->n_outputs = prog->n_outputs;
     return FBS_OK;
@@ -837,7 +836,7 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     if (f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad bootstrap range");
     if (f_begin == f_end) return FBS_OK;   // (covers s_count == 0)
     // A level with shared rotations: into the wire slots it runs whole (the tables of one source are cut from one accumulator
-    // right after the rotations).  Into rows it can be SLICED: rows are then 2N words (fbs_layout.row_words), an ordinary gate
+    // right after the rotations).  Into rows it can be SLICED: rows are then (k + 1) N words (fbs_layout.row_words), an ordinary gate
     // leaves its ciphertext in its row and a shared rotation its whole accumulator -- the unit dealt out across GPUs is the
     // rotation -- and fbs_level_scatter_dev cuts the tables out once every row is there.
     if (b.n_shared && !d_rows && (f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
@@ -858,7 +857,7 @@ int fbs_level_bootstrap_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, 
     gv.table_ids = b.d_table;
     gv.source_of = b.d_source_of;
     gv.out_rows = d_rows;
-    gv.row_words = (d_rows && prog->fused) ? 2 * ctx->N : 0;
+    gv.row_words = (d_rows && prog->fused) ? (ctx->p.k + 1) * ctx->N : 0;
     gv.T = T;
     gv.s_begin = s_begin;
     gv.s_count = s_count;
@@ -891,10 +890,10 @@ int fbs_level_scatter_dev(fbs_ctx *ctx, const fbs_prog *prog, uint32_t level, ui
     const BootStage &b = prog->boot[level];
     if (!d_rows || f_begin > f_end || f_end > (size_t)b.n_gates * s_count) return set_error(ctx, FBS_E_INVALID, "bad row range");
     if (!prog->fused) return dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, 0, pick(ctx, stream));
-    // fused: rows of 2N words; the tables of shared rotations are cut out of the gathered accumulators, which takes every row
+    // fused: rows of (k + 1) N words; the tables of shared rotations are cut out of the gathered accumulators, which takes every row
     if (b.n_shared && (f_begin != 0 || f_end != (size_t)b.n_gates * s_count))
         return set_error(ctx, FBS_E_INVALID, "scattering a level of a fused program takes all of its rows");
-    rc = dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, 2 * ctx->N, pick(ctx, stream));
+    rc = dev_scatter_rows(ctx, d_wires, T, s_begin, s_count, b.d_dst, d_rows, f_begin, f_end - f_begin, (ctx->p.k + 1) * ctx->N, pick(ctx, stream));
     if (rc != FBS_OK || !b.n_shared) return rc;
     return dev_multi_extract(ctx, prog->tv, d_rows, d_wires, T, s_begin, s_count, b.n_extract, b.d_x_gate, b.d_x_table, b.d_x_dst,
                              pick(ctx, stream));
@@ -916,10 +915,10 @@ static int run_levels(fbs_ctx *ctx, const fbs_prog *prog, uint64_t *d_wires, siz
 static int reserve_wires(fbs_ctx *ctx, const fbs_prog *prog, size_t T, size_t *chunk) {
     const size_t ctw = ctx->D + 1;
     const size_t per_sample = (size_t)prog->n_slots * ctw * 8 + (size_t)std::max(1u, prog->max_sources) * (ctx->p.n + 1) * 4 +
-                              (size_t)prog->max_shared * 2 * ctx->N * 8;
+                              (size_t)prog->max_shared * (ctx->p.k + 1) * ctx->N * 8;
     size_t free_b = 0, total_b = 0;
     FBS_HIP(ctx, hipMemGetInfo(&free_b, &total_b));
-    size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4 + ctx->acc_capacity * 2 * ctx->N * 8;
+    size_t have = free_b + ctx->wires_capacity * 8 + ctx->ms_capacity * (ctx->p.n + 1) * 4 + ctx->acc_capacity * (size_t)(ctx->p.k + 1) * ctx->N * 8;
     // test hook: FBS_WIRE_BUDGET_MB caps what the wire slots may take, so that the chunked path runs at small sizes
     if (const char *cap = getenv("FBS_WIRE_BUDGET_MB")) have = std::min<size_t>(have, (size_t)std::max(1, atoi(cap)) << 20);
     const size_t Tc = std::min<size_t>(T, std::max<size_t>(1, (size_t)(0.6 * (double)have) / per_sample));

@@ -28,7 +28,8 @@ __device__ __forceinline__ uint64_t *gate_out(const GateView &gv, size_t i, uint
 }
 
 // fused programs: the scratch row a rotation of TV_0 leaves its whole accumulator in, or null for an ordinary gate
-__device__ __forceinline__ uint64_t *gate_acc(const GateView &gv, size_t i, uint32_t N) {
+// (`acc_words` = (k + 1) N: the whole GLWE accumulator, mask polynomials then body)
+__device__ __forceinline__ uint64_t *gate_acc(const GateView &gv, size_t i, uint32_t acc_words) {
     const bool in_row = gv.out_rows && gv.row_words;   // a fused level cut across GPUs: the accumulator goes into the gate's row
     if (!gv.acc_rows && !in_row) return nullptr;
     const size_t f = gv.f_begin + i;
@@ -36,7 +37,7 @@ __device__ __forceinline__ uint64_t *gate_acc(const GateView &gv, size_t i, uint
     const uint32_t d = gv.dst_slot[g];
     if (!(d & 0x80000000u)) return nullptr;
     if (in_row) return gv.out_rows + i * gv.row_words;
-    return gv.acc_rows + ((size_t)(d & 0x7FFFFFFFu) * gv.s_count + s) * 2 * N;
+    return gv.acc_rows + ((size_t)(d & 0x7FFFFFFFu) * gv.s_count + s) * acc_words;
 }
 
 }  // namespace fbs

@@ -66,7 +66,7 @@ struct GateView {
                                 // a shared rotation then leaves its whole accumulator in its row (it travels with the gather)
     // Several tables on ONE blind rotation (fused programs, fbs_program_load_ex): a gate whose dst_slot has bit 31 set is
     // the rotation of the table-independent test vector TV_0 for a source that several tables read; it leaves its whole
-    // accumulator in row (dst & 0x7fffffff) * s_count + sample of acc_rows ([row][2][N]) for k_multi_extract.
+    // accumulator in row (dst & 0x7fffffff) * s_count + sample of acc_rows ([row][k + 1][N]) for k_multi_extract.
     uint64_t *acc_rows;
     size_t T;                   // samples per wire in the buffers (stride)
     size_t s_begin, s_count;    // sample window of the launch

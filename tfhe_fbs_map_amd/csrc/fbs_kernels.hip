@@ -585,35 +585,36 @@ __global__ __launch_bounds__(256) void k_scatter_rows(uint64_t *wires, size_t T,
     for (uint32_t j = threadIdx.x; j < ct_words; j += 256) out[j] = in[j];
 }
 
-// Several tables on one blind rotation (fused programs): the rotation of TV_0 left the GLWE accumulator (A, B) in a scratch
+// Several tables on one blind rotation (fused programs): the rotation of TV_0 left the GLWE accumulator (A_0 .. A_(k-1), B) in a scratch
 // row; table F's ciphertext is SampleExtract_0((A, B) * D_F) + post_F with D_F the small integer polynomial of
 // host_build_tv_diff, given as (position, value) pairs.  Coefficient m of X^i * P is P[m - i], negated when it wrapped;
 // the extracted ciphertext holds A'_0, -A'_(N-1), .., -A'_1 and B'_0.  d * word < 2^16 * 2^46 summed in 64 bits (the loader
 // fuses only tables with sum |d| < 2^16), one reduction per output word.  HBM-bound copy work, a few hundred KB per row.
 __global__ __launch_bounds__(256) void k_multi_extract(const uint64_t *acc_rows, uint64_t *wires, size_t T, size_t s_begin,
-                                                       size_t s_count, uint32_t N, const uint32_t *x_row, const uint32_t *x_table,
+                                                       size_t s_count, uint32_t N, uint32_t k, const uint32_t *x_row, const uint32_t *x_table,
                                                        const uint32_t *x_dst, const uint32_t *diff_pos, const int32_t *diff_val,
                                                        const uint32_t *diff_n, uint32_t diff_cap, const uint64_t *post) {
     const size_t e = blockIdx.x / s_count, s = blockIdx.x % s_count;
-    const uint32_t tab = x_table[e];
-    const uint64_t *A = acc_rows + ((size_t)x_row[e] * s_count + s) * 2 * N, *B = A + N;
-    uint64_t *out = wires + ((size_t)x_dst[e] * T + s_begin + s) * (N + 1);
+    const uint32_t tab = x_table[e], D = k * N;
+    const uint64_t *acc = acc_rows + ((size_t)x_row[e] * s_count + s) * (size_t)(k + 1) * N;   // A_0 .. A_(k-1), B
+    uint64_t *out = wires + ((size_t)x_dst[e] * T + s_begin + s) * (D + 1);
     const uint32_t *pos = diff_pos + (size_t)tab * diff_cap;
     const int32_t *val = diff_val + (size_t)tab * diff_cap;
     const uint32_t w = diff_n[tab];
-    for (uint32_t j = threadIdx.x; j <= N; j += 256) {
-        const uint64_t *P = j == N ? B : A;
-        const uint32_t m = (j == 0 || j == N) ? 0u : N - j;   // coefficient of the product this word comes from
+    for (uint32_t j = threadIdx.x; j <= D; j += 256) {
+        const uint32_t c = j / N, jj = j - c * N;               // word jj of mask polynomial c; j == D: the body
+        const uint64_t *P = acc + (size_t)c * N;                // (c == k for the body: the accumulator's last polynomial)
+        const uint32_t m = jj == 0 ? 0u : N - jj;               // coefficient of the product this word comes from
         int64_t sum = 0;
         for (uint32_t i = 0; i < w; i++) {
             const uint32_t at = pos[i];
             const int64_t term = (int64_t)val[i] * (int64_t)(m >= at ? P[m - at] : P[m + N - at]);
             sum += m >= at ? term : -term;
         }
-        if (j != 0 && j != N) sum = -sum;
+        if (jj != 0) sum = -sum;
         int64_t r = sum % (int64_t)FQ;
         if (r < 0) r += (int64_t)FQ;
-        out[j] = j == N ? fq_add((uint64_t)r, post[tab]) : (uint64_t)r;
+        out[j] = j == D ? fq_add((uint64_t)r, post[tab]) : (uint64_t)r;
     }
 }
 
@@ -878,7 +879,7 @@ int dev_multi_extract(fbs_ctx *ctx, const fbs_tvset *tv, const uint64_t *d_acc_r
     const size_t blocks = (size_t)n_extract * s_count;
     if (blocks == 0) return FBS_OK;
     if (blocks > 0x7FFFFFFFull) return set_error(ctx, FBS_E_INVALID, "more than 2^31 rows in one launch");
-    hipLaunchKernelGGL(k_multi_extract, dim3((unsigned)blocks), dim3(256), 0, stream, d_acc_rows, d_wires, T, s_begin, s_count, ctx->N,
+    hipLaunchKernelGGL(k_multi_extract, dim3((unsigned)blocks), dim3(256), 0, stream, d_acc_rows, d_wires, T, s_begin, s_count, ctx->N, ctx->p.k,
                        d_x_row, d_x_table, d_x_dst, tv->d_diff_pos, tv->d_diff_val, tv->d_diff_n, tv->diff_cap, tv->d_post);
     FBS_HIP(ctx, hipGetLastError());
     return FBS_OK;

@@ -60,7 +60,7 @@ class GpuBackend:
         return torch.empty((self.prog.n_slots * max(1, T), self.ctw), dtype=torch.int64, device=self.device)
 
     def new_rows(self, rows):
-        """rows of the level calls' send / gather buffers: one ciphertext each, or 2N words for a fused program (a shared
+        """rows of the level calls' send / gather buffers: one ciphertext each, or (k + 1) N words for a fused program (a shared
         rotation's accumulator travels in its row: include/fbs_exec.h FBS_LOAD_FUSE_TABLES)"""
         return torch.empty((max(1, rows), self.prog.row_words), dtype=torch.int64, device=self.device)
 

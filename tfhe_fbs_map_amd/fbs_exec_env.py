@@ -118,7 +118,8 @@ class ExecConfig:
     # round 4 it is ahead at EVERY launch size: one bootstrap on the twelve waves of a workgroup (k_blind_rotate_cu_k2) takes
     # 2.0-2.4 ms per launch of up to one bootstrap per CU where the k = 1 sets' whole-CU kernels take 2.6-2.9.  So the choice no
     # longer depends on how wide a program's levels are (rounds 3's `wide_level`), nor on how many ranks it is cut over: every
-    # rank of a sharded run derives the same set from (p, norm2).  Shared rotations (fuse_tables) are built for k = 1 only.
+    # rank of a sharded run derives the same set from (p, norm2) -- shared rotations (fuse_tables) included: the accumulator rows
+    # and the extraction kernel are general in k since round 4.
     glwe_dims: tuple = (1, 2)
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
@@ -170,7 +171,7 @@ class ExecConfig:
         fstats = env.fusion_stats(p) if self.fuse_tables is not False else None
         if fstats is None or fstats["nb_rotation"] == stats["nb_bootstrap"] or (self.fuse_tables is None and self.params is not None):
             return self._chosen(self.params_choice(p, stats["norm2_linprod"]), False, stats["norm2_linprod"], stats["nb_bootstrap"], samples, ranks)
-        fused = self.params_choice(p, fstats["norm2_linprod"], glwe_dims=(1,))      # shared rotations: k = 1
+        fused = self.params_choice(p, fstats["norm2_linprod"])
         if self.fuse_tables is not True:
             plain = self.params_choice(p, stats["norm2_linprod"])
             if not bootstrap_cost(fused) * fstats["nb_rotation"] < bootstrap_cost(plain) * stats["nb_bootstrap"]:

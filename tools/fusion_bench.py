@@ -65,7 +65,7 @@ def main():
         out["fused" if fuse else "plain"] = {
             "fused": fused, "seconds": round(dt, 3), "rotations": prog.n_rotations, "bootstraps": prog.n_bootstrap,
             "gate_bootstraps_per_s": round(prog.n_bootstrap * T / dt), "rotations_per_s": round(prog.n_rotations * T / dt),
-            "params": dict(n=prm.n, N=prm.N, l=prm.l_bsk, beta=prm.beta_bsk, t=prm.t_ksk, gamma=prm.gamma_ksk, bsk_group=prm.bsk_group),
+            "params": dict(n=prm.n, N=prm.N, k=prm.k, l=prm.l_bsk, beta=prm.beta_bsk, t=prm.t_ksk, gamma=prm.gamma_ksk, bsk_group=prm.bsk_group),
             "security_bits": round(security_bits(prm), 1), "margin_sigmas": round(margin_sigmas(prm, norm2), 2), "all_sums_correct": True}
         ctx.close()
     out["speedup"] = round(out["plain"]["seconds"] / out["fused"]["seconds"], 3)
