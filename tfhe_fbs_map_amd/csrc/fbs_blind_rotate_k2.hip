@@ -229,7 +229,8 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 //     FIRST DURING THE STEP BEFORE (after its hand-over barrier: the words stream in behind the inverse transform),
 //       second ahead of the forward transform's last four stages                           1.96 / 2.21   <- this kernel
 //     ... second at the top of the step / one step ahead as well (after the re-deal back)  2.26 / 2.48,  2.17 / 2.38
-// (more loads in flight than one register pair's is worse every time).  Two rounds of it serve 512 bootstraps in 4.2 ms (the
+// (more loads in flight than one register pair's is worse every time; so is asking for the three psi^(e o_lane) of the NEXT step
+// behind the hand-over barrier as well: 2.06 / 2.36 -> 2.17 / 2.42 ms, same box, twice).  Two rounds of it serve 512 bootstraps in 4.2 ms (the
 // three-waves-per-bootstrap kernel: 4.85).  The same shape on SIX waves (two per component, 512-point parts at 8 coefficients per
 // lane, 223 registers, 89 KB of LDS: one workgroup per CU all the same) was built and measured: 2.91 ms at 64 and at 256 -- dropped.
 // Evaluation points: array position P = 256 w + j of part w holds the value at psi^(2 bitrev10(P) + 1), and after the part's
@@ -309,10 +310,20 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
     };
     using Pair0 = std::integral_constant<int, 0>;
     using Pair1 = std::integral_constant<int, 1>;
+    auto lookup = [&](uint32_t ea, uint32_t eb, double (&out)[3]) {
+        const uint32_t ee[3] = {ea, eb, (ea + eb) & (2u * N - 1u)};
+#pragma unroll
+        for (int jj = 0; jj < 3; jj++) {
+            const uint32_t x = __umul24(ee[jj], o_lane) & (2u * N - 1u);
+            const double v = a.psi_pow[x & (N - 1)];
+            out[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));
+        }
+    };
     const uint32_t n_pairs = a.n / 2;
     double2 kw0[3][K1], kw1[3][K1];
     request(0, Pair0{}, kw0);
     uint32_t e0_next = ms[0], e1_next = ms[1];
+
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
         e[0] = __builtin_amdgcn_readfirstlane(e0_next);
@@ -328,12 +339,7 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
 
         // ---- psi^(e o_lane) for the three exponents: one look-up each (psi^(x + N) = -psi^x) -------------------------------------
         double A[3];
-#pragma unroll
-        for (int jj = 0; jj < 3; jj++) {
-            const uint32_t x = __umul24(e[jj], o_lane) & (2u * N - 1u);
-            const double v = a.psi_pow[x & (N - 1)];
-            A[jj] = __hiloint2double(__double2hiint(v) ^ (int)((x << (31 - LOGN)) & 0x80000000u), __double2loint(v));
-        }
+        lookup(e[0], e[1], A);
 
         // ---- ACC_c itself, rounded to the closest multiple of q / B; the two cross stages; re-deal; private transform -----------
         double x[1][E];
@@ -406,6 +412,7 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] = prod[0][m] + mine[64u * m + ln] + mine2[64u * m + ln];
         request(i_next, Pair0{}, kw0);   // the NEXT step's first register pair: it streams in behind the inverse transform
+
         tw.inverse(own, mine, ln, LaneNtt256::NoHook{});   // three products below 0.8 q each: centred first by the transform
         Part::sync();
 #pragma unroll
