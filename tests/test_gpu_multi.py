@@ -89,6 +89,26 @@ def test_bench_two_gpus_reports_rccl_legs():
     assert d["sharded"]["params"]["security_bits_estimate"] >= 127.9
 
 
+@pytest.mark.parametrize("flavour", ["", "fused", "k2"])
+def test_the_worker_itself_on_one_rank(tmp_path, flavour):
+    """The worker of the tests above with world size 1 on the nccl backend -- on ANY GPU box, the one-GPU ones included: the file
+    that waits for a multi-GPU node is at least run end to end (process group, layouts, the npz it hands back) where this build
+    can run it."""
+    out = str(tmp_path / "res1.npz")
+    name, T = ("adder8__basic_p2", 4) if flavour == "fused" else ("adder8__search_p7", 5)
+    rc = launch(1, [os.path.join(ROOT, "tests", "dist_multi_worker.py"), name, str(T), out] + ([flavour] if flavour else []))
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    z = np.load(out)
+    assert str(z["backend"]) == "nccl" and int(z["world"]) == 1
+    rec = load_fixture(name)
+    _, expect = subsample(rec, T)
+    low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
+    for k, w in enumerate(low["out_wire"]):
+        if w >= 0:
+            assert np.array_equal(z["gate"][k], z["ref"][k]) and np.array_equal(z["sample"][k], z["ref"][k])
+            assert np.array_equal(z["dec"][k], expect[low["out_names"][k]])
+
+
 def test_skips_say_why_on_a_one_gpu_box():
     """(so that a one-GPU run shows this module was considered, and what it would take to run it)"""
     if gpu_count() >= 2:

@@ -31,7 +31,7 @@ for name in fixture_names():
     prog = next(reversed(cfg._programs.values()))[0] if cfg._programs else None      # the program this eval loaded or reused
     rows.append(dict(name=name, ok=bool(ok), nb_bootstrap=st["nb_bootstrap"], norm2=st["norm2_linprod"], seconds=round(time.time() - t0, 2),
                      shared_rotations=bool(prog and prog.fused), rotations=prog.n_rotations if prog else None,
-                     N=prog.ctx.params.N if prog else None))
+                     N=prog.ctx.params.N if prog else None, k=prog.ctx.params.k if prog else None))
     if not ok:
         bad.append((name, "wrong output"))
     if len(cfg._contexts) > 6:                     # keys are large: keep a few contexts
@@ -42,7 +42,7 @@ for name in fixture_names():
 sets = {}
 summary = dict(samples=T, fixtures=len(rows), all_ok=not bad, failures=bad, bootstraps=sum(r["nb_bootstrap"] for r in rows) * T,
                rotations=sum((r["rotations"] or 0) for r in rows) * T, programs_with_shared_rotations=sum(r["shared_rotations"] for r in rows),
-               poly_sizes=sorted({r["N"] for r in rows if r["N"]}),
+               poly_sizes=sorted({r["N"] for r in rows if r["N"]}), programs_at_glwe_dimension_2=sum(1 for r in rows if r.get("k") == 2),
                seconds=round(time.time() - t_all, 1), rows=rows)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(summary, open("gpurun_out/%s_all_fixtures.json" % ("reduced_noise" if os.environ.get("REDUCED_NOISE") else "secure"), "w"), indent=1)
