@@ -15,13 +15,15 @@
 // ADDS its products straight into the three components' buffers with ds_add_f64 -- exact on integer-valued doubles below 2^53,
 // so the order in which the three additions land does not matter -- and after a second barrier each wave reads its total back
 // and inverts it.  Two workgroup barriers per step, none inside the transforms.
-// (Round 4, measured and not adopted: the next step's first register pair of key words requested behind the read-back, as the
+// (Round 4, measured and not adopted: TWO six-wave workgroups per CU instead of one of twelve waves (<10,2> at every size: 72 KB of LDS
+// and 166 registers each would allow it) -- 9.5 against 7.2 ms per 1 024; the next step's first register pair of key words requested behind the read-back, as the
 // twelve-wave shape below does -- 168 registers with 160 bytes spilled instead of 12: 7.60 against 7.21 ms per 1 024; and the
 // monomial factors as psi^(e o_lane) (ONE gather per exponent) times the wave-uniform psi^(e c_m) read through the scalar cache, in
 // the place of a gather from the table in LDS per register pair and exponent: 7.40 against 7.24 ms, same box, twice.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
 
 #include "fbs_blind_rotate_cu.hpp"
@@ -203,6 +205,24 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
     }
 }
 
+// -DFBS_CU_TRACE (experiments only, tools/trace_k2.sh): cycles per phase of a step, per wave of workgroup 0, summed over the rotation
+#ifdef FBS_CU_TRACE
+__device__ unsigned long long g_k2_trace[12 * 16];
+#define K2_TRACE_INIT unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define K2_TRACE(k)                                                  \
+    {                                                                \
+        const unsigned long long now = __builtin_readcyclecounter(); \
+        tr_acc[k] += now - tr_t;                                     \
+        tr_t = now;                                                  \
+    }
+#define K2_TRACE_FLUSH                                               \
+    if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0)                 \
+        for (int k = 0; k < 10; k++) g_k2_trace[(threadIdx.x >> 6) * 16 + k] = tr_acc[k];
+#else
+#define K2_TRACE_INIT
+#define K2_TRACE(k)
+#define K2_TRACE_FLUSH
+#endif
 // ---------------------------------------------------------------------------------------------
 // The LATENCY shape: ONE k = 2 bootstrap on the twelve waves of a workgroup -- what a launch that leaves most of the chip empty
 // wants (a rank's slice of a level of a sharded circuit, a narrow level, the leftovers of a round): a bootstrap is n / 2 dependent
@@ -238,6 +258,13 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 // LOWEST bits of P, the two HIGHEST of its bit reversal, so 2 bitrev(P) + 1 = o_lane + 512 k_m with k_m = j1 + 2 j0, and
 // psi^512 = R is a primitive FOURTH root of unity: zeta_m^e = psi^(e o_lane) R^(e k_m).  ONE table look-up per lane and exponent;
 // R^e is wave-uniform (picked among 1, R, -1, -R by scalar instructions) and multiplied in once.
+// WHERE A STEP'S TIME GOES (-DFBS_CU_TRACE, tools/trace_k2.sh, profiles/r04/k2_cu_phase_trace.txt; cycle stamps per wave of workgroup 0): of
+// ~17 k cycles per step the forward transform takes 5.7 k, the products 4.5 k, the inverse 4.4 k for the wave that finishes last; the three
+// waves of a SIMD (component 0, 1, 2: oldest first) do NOT advance together -- component 0 is issued first whenever it is ready and waits
+// 2.1 M of a rotation's 6.2 M cycles at the barriers, component 2 never waits.  Handing the lead over in the middle of every stretch
+// (s_setprio by component: the youngest leads the first half, the oldest the second -- what helps the k = 1 shape's TWO waves per SIMD)
+// moves the waiting around and makes the rotation LONGER: 2.07 -> 2.39-2.54 ms per launch of 64.  The transforms are dependent chains
+// (two butterflies per stage at 4 coefficients per lane) that no order of three such chains fills the pipe with; measured, not adopted.
 // LDS (doubles): [3][N] re-deal + private forward exchange; [3][2][N] hand-over slots -- slot 0 doubles as the private inverse
 // exchange and the re-deal back (wave w receives in the words it alone touches until the re-deal, as in k_blind_rotate_cu_pairs):
 // 72 KB.
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
     double2 kw0[3][K1], kw1[3][K1];
     request(0, Pair0{}, kw0);
     uint32_t e0_next = ms[0], e1_next = ms[1];
-
+    K2_TRACE_INIT
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
         e[0] = __builtin_amdgcn_readfirstlane(e0_next);
@@ -333,9 +360,10 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
         const uint32_t i_next = i + 1 < n_pairs ? i + 1 : i;   // (the last step asks for its own row again: in bounds, unused)
         if (e[0] == 0 && e[1] == 0) {                       // the bundle is zero (uniform over the workgroup: one bootstrap)
             request(i_next, Pair0{}, kw0);
-            continue;
+                continue;
         }
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
+        K2_TRACE(0)
 
         // ---- psi^(e o_lane) for the three exponents: one look-up each (psi^(x + N) = -psi^x) -------------------------------------
         double A[3];
@@ -358,31 +386,33 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < PARTS; q++) xf[q * M + t] = x[0][q];
+        K2_TRACE(1)
         __syncthreads();
+        K2_TRACE(2)
         double *bufs[1] = {xf + w * M};   // the words only this wave reads: its private exchange buffer from here on
 #pragma unroll
         for (int m = 0; m < E; m++) x[0][m] = bufs[0][ln + 64u * m];
-        LaneNtt256::forward_multi<1, 0>(x, bufs, ln, tw.f, [&] { request(i, Pair1{}, kw1); });
-
         // ---- the monomial factors: psi^(e o_lane) and its product with R^e (see above); the sign (-1)^e as a bit operation --------
         // (Written as selects among +-A, +-A R the compiler builds a table per exponent in SCRATCH memory and indexes it: six
         // stores and three dependent loads per step, each behind an s_waitcnt vmcnt(0) that also waits for the key words in flight.)
         double AR[3];
+        auto root_powers = [&] {
 #pragma unroll
-        for (int jj = 0; jj < 3; jj++) {
-            const uint32_t r = e[jj] & 3u;                                       // wave-uniform
-            const double re = r == 0u ? 1.0 : r == 1u ? root : r == 2u ? -1.0 : -root;
-            AR[jj] = fp_mulmod(A[jj], re);
-        }
+            for (int jj = 0; jj < 3; jj++) {
+                const uint32_t r = e[jj] & 3u;                                       // wave-uniform
+                const double re = r == 0u ? 1.0 : r == 1u ? root : r == 2u ? -1.0 : -root;
+                AR[jj] = fp_mulmod(A[jj], re);
+            }
+        };
         // zeta^e - 1 for register m = (j1 j0): k_m = j1 + 2 j0, zeta_m^e = A R^(e k_m): m = 0: A; 1: (-1)^e A; 2: A R^e; 3: (-1)^e A R^e
         auto mono = [&](int jj, int m) {
             const double v = (m & 2) ? AR[jj] : A[jj];
             if (!(m & 1)) return v - 1.0;
             return __hiloint2double(__double2hiint(v) ^ (int)(e[jj] << 31), __double2loint(v)) - 1.0;
         };
-        // ---- bundle x digits, register pair by register pair: products for the three output components (rotated order) ---------
-        double prod[K1][E];
-        auto consume = [&](auto jc, const double2 (&k)[3][K1]) {
+        // ---- the bundle words of a register pair (they do not depend on the digits), then their products with the digits' evaluations:
+        // products for the three output components (rotated order)
+        auto bundle = [&](auto jc, const double2 (&k)[3][K1], double (&w)[K1][2]) {
             constexpr int j = decltype(jc)::value;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -390,16 +420,32 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
                 const double mo[3] = {mono(0, m), mono(1, m), mono(2, m)};
 #pragma unroll
                 for (int d = 0; d < K1; d++) {
-                    // bundle word: lazy sum of three exact products (< 2.4 q); |x| < 2^49.3, so the product below stays exact
+                    // lazy sum of three exact products (< 2.4 q); |x| < 2^49.3, so its product with a digit's evaluation stays exact
                     double wsum = fp_mulmod(r ? k[0][d].y : k[0][d].x, mo[0]);
 #pragma unroll
                     for (int jj = 1; jj < 3; jj++) wsum += fp_mulmod(r ? k[jj][d].y : k[jj][d].x, mo[jj]);
-                    prod[d][m] = fp_mulmod(x[0][m], wsum);
+                    w[d][r] = wsum;
                 }
             }
         };
-        consume(Pair0{}, kw0);
-        consume(Pair1{}, kw1);
+        double prod[K1][E], w0[K1][2], w1[K1][2];
+        auto finish = [&](auto jc, const double (&w)[K1][2]) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int d = 0; d < K1; d++) prod[d][2 * j + r] = fp_mulmod(x[0][2 * j + r], w[d][r]);
+        };
+        // (Measured and not adopted: the first pair's bundle -- 126 instructions that need nothing from the transform -- INSIDE the forward
+        // transform, ahead of its last four stages, and both pairs' with the second pair's key words asked for a step ahead as well:
+        // 2.06 / 2.35 -> 2.30 / 2.50 and 2.25 / 2.45 ms per launch of 64 / 256, same box, twice.  profiles/r04/k2_cu_bundle_in_transform_ab.txt)
+        LaneNtt256::forward_multi<1, 0>(x, bufs, ln, tw.f, [&] { request(i, Pair1{}, kw1); });
+        K2_TRACE(3)
+        root_powers();
+        bundle(Pair0{}, kw0, w0);
+        finish(Pair0{}, w0);
+        bundle(Pair1{}, kw1, w1);
+        finish(Pair1{}, w1);
 
         // ---- hand the other two components theirs; sum; private inverse; re-deal back; joining stages; accumulate ---------------
 #pragma unroll
@@ -407,17 +453,20 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
             to_c1[64u * m + ln] = prod[1][m];
             to_c2[64u * m + ln] = prod[2][m];
         }
+        K2_TRACE(4)
         __syncthreads();
+        K2_TRACE(5)
         double own[E];
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] = prod[0][m] + mine[64u * m + ln] + mine2[64u * m + ln];
         request(i_next, Pair0{}, kw0);   // the NEXT step's first register pair: it streams in behind the inverse transform
-
         tw.inverse(own, mine, ln, LaneNtt256::NoHook{});   // three products below 0.8 q each: centred first by the transform
         Part::sync();
 #pragma unroll
         for (int m = 0; m < E; m++) mine[ln + 64u * m] = own[m];
+        K2_TRACE(6)
         __syncthreads();
+        K2_TRACE(7)
 #pragma unroll
         for (int q = 0; q < PARTS; q++) own[q] = back[q * M + t];
 #pragma unroll
@@ -434,7 +483,9 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
         }
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
+        K2_TRACE(8)
     }
+    K2_TRACE_FLUSH
 
     // ---- sample extraction of coefficient 0 (two mask polynomials, the body), plus the table's constant -----------------
     if (!live) return;
@@ -475,6 +526,19 @@ bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
         b.bsk_hat = reinterpret_cast<const double *>(ctx->d_bsk_hat_small);
         *kernel = "k_blind_rotate_cu_k2";
         hipLaunchKernelGGL(k_blind_rotate_cu_k2, dim3((unsigned)a.count), dim3(768), 0, stream, b);
+#ifdef FBS_CU_TRACE
+        {
+            unsigned long long h[12 * 16];
+            if (hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k2_trace), sizeof h) == hipSuccess) {
+                fprintf(stderr, "trace k_blind_rotate_cu_k2 (cycles per phase, workgroup 0, whole rotation; wave = 4 component + part):\n");
+                for (int w = 0; w < 12; w++) {
+                    fprintf(stderr, "  wave %2d:", w);
+                    for (int k = 0; k < 9; k++) fprintf(stderr, " %9llu", h[w * 16 + k]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
+#endif
         return true;
     }
     // the three-waves-per-bootstrap kernel: up to one bootstrap per CU one per workgroup; up to two: two; beyond: four
