@@ -43,6 +43,13 @@ def test_headline_line_has_the_contract_fields():
     assert s["decrypt_ok"] and s["params"]["security_bits_estimate"] >= 127.9 and s["margin_sigmas_at_norm2_70"] >= 6.0
     assert s["n1024_p4"]["decrypt_ok"] and s["n1024_p4"]["params"]["N"] == 1024
     assert s["p31"]["decrypt_ok"] and s["p31"]["params"]["security_bits_estimate"] >= 127.9 and s["p31"]["params"]["p"] == 31
+    # every 128-bit leg holds a sample of its TIMED batch to the scalar oracle, word for word; at batch 256 the default
+    # set runs on the twelve-wave latency shape; and the deployable number sits at the top level beside the benchmark shape
+    legs = [s, s["k1"], s["one_key_bit_per_step"], s["n1024_p4"], s["n1024_p4"]["k2"], s["p31"], s["p31"]["one_key_bit_per_step"]]
+    assert all(leg["bit_exact_vs_oracle"] is True and "scalar oracle" in leg["oracle_sample"] for leg in legs)
+    assert s["params"]["k"] == 2 and s["blind_rotate_kernel"] == "k_blind_rotate_cu_k2" and s["k1"]["params"]["k"] == 1
+    v = d["value_secure"]
+    assert v["value"] == s["value"] and v["bit_exact_vs_oracle"] and v["params"]["security_bits_estimate"] >= 127.9 and v["params"]["k"] == 2
     f = d["shared_rotations"]                                                # several tables on one blind rotation
     assert f["plain"]["all_sums_correct"] and f["fused"]["all_sums_correct"]
     assert f["fused"]["blind_rotations"] < f["fused"]["tables"] == f["plain"]["tables"] == f["plain"]["blind_rotations"]

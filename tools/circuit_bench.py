@@ -13,9 +13,9 @@ for name, T in (("mul16__search_p15", 1000), ("adder128__search_p15", 1000), ("t
     ins, expect = subsample(rec, T)
     if os.environ.get("SECURE"):               # the 128-bit set of params.choose_params at the program's (p, norm2)
         from tfhe_fbs_map_amd import choose_params
-        prm = choose_params(15, env.stats()["norm2_linprod"])
-        print("  chosen: n=%d N=%d l=%d beta=%d t=%d gamma=%d, %d key bit(s) per step" % (
-            prm.n, prm.N, prm.l_bsk, prm.beta_bsk, prm.t_ksk, prm.gamma_ksk, prm.bsk_group))
+        prm = choose_params(15, env.stats()["norm2_linprod"], glwe_dims=(1, 2))       # what ExecConfig() asks for
+        print("  chosen: n=%d N=%d k=%d l=%d beta=%d t=%d gamma=%d, %d key bit(s) per step" % (
+            prm.n, prm.N, prm.k, prm.l_bsk, prm.beta_bsk, prm.t_ksk, prm.gamma_ksk, prm.bsk_group))
     else:
         prm = P1024
     ctx = Context(prm, seed=1)

@@ -12,7 +12,11 @@ from tfhe_fbs_map_amd import P1024, Context                                 # no
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-ctx = Context(P1024, seed=1)
+prm = P1024
+if os.environ.get("SECURE"):                  # the default 128-bit set for p = 15 (GLWE dimension 2: ciphertexts of 2 N + 1 words)
+    from tfhe_fbs_map_amd import choose_params
+    prm = choose_params(15, 70, glwe_dims=(1, 2))
+ctx = Context(prm, seed=1)
 rng = np.random.default_rng(42)
 tables = [[0] + [int(v) for v in rng.integers(0, 2, 14)] for _ in range(16)]
 tv = ctx.tvset(tables)
