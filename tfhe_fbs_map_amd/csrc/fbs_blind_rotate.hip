@@ -206,7 +206,7 @@ __global__ __launch_bounds__((2 << LL) * FPW) __attribute__((amdgpu_waves_per_eu
             for (int m = 0; m < E; m++)
                 x[m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);   // balanced digit in [-B/2, B/2)
             // (buffer loads, KeyRows: the step's rows behind one resource, the polynomial picked by a scalar byte offset)
-            const KeyRows keys(a.bsk_hat + (size_t)i * rows * 2 * N);
+            const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(i) * rows * 2 * N);
             const uint32_t krow = ((comp * a.l + (uint32_t)lv) * 2u) * (uint32_t)(N * 8);
             const uint32_t k_own = krow + comp * (uint32_t)(N * 8), k_oth = krow + (comp ^ 1u) * (uint32_t)(N * 8);
             // The first half of the "own" key polynomial is requested before the last butterfly group of the transform
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(2 << LL) __attribute__((amdgpu_waves_per_eu(2))) vo
             if constexpr (!ONE_LEVEL) asm volatile("" : "+s"(e_lv[0]), "+s"(e_lv[1]), "+s"(e_lv[2]));
             // the step's key rows (three samples of `rows` rows of two polynomials) behind one buffer resource; own / partner's
             // polynomial of this component's row of sample jj: scalar byte offsets
-            const KeyRows keys(a.bsk_hat + (size_t)i * 3 * rows * 2 * N);
+            const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(i) * 3 * rows * 2 * N);
             uint32_t k_own[3], k_oth[3];
 #pragma unroll
             for (int jj = 0; jj < 3; jj++) {

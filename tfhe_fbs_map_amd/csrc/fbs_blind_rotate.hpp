@@ -56,6 +56,12 @@ __device__ __forceinline__ void lead_if(uint32_t turn, uint32_t slot) {
 // polynomial are reached through the instruction's immediate offset -- no 64-bit address arithmetic on the vector pipe and no
 // register pair per address (flat global loads: 78 of the 2 873 vector instructions of a k_blind_rotate_pairs<11,7,4> step and
 // more than thirty registers went into addresses).  `base` must be wave-uniform.
+// -DFBS_EXP_HOT_KEYS=1 (experiments only: WRONG results): every step reads the key rows of step 0 or 1, which stay in L2 -- what a
+// launch would take if no key word ever came from further away than L2
+#ifndef FBS_EXP_HOT_KEYS
+#define FBS_EXP_HOT_KEYS 0
+#endif
+#define FBS_KEY_STEP(i) (FBS_EXP_HOT_KEYS ? ((i) & 1u) : (i))
 struct KeyRows {
     __amdgpu_buffer_rsrc_t rsrc;
     __device__ __forceinline__ explicit KeyRows(const double *base)

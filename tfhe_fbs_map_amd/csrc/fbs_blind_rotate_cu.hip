@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
     constexpr bool PREFETCH = FBS_CU_PREFETCH != 0 && !LEAN;
     double2 ko[NL][E / 2], kt[NL][E / 2];
     auto request_keys = [&](uint32_t step) {
-        const KeyRows rows_of(a.bsk_hat + ((size_t)step * rows + comp * NL) * 2 * N);
+        const KeyRows rows_of(a.bsk_hat + ((size_t)FBS_KEY_STEP(step) * rows + comp * NL) * 2 * N);
 #pragma unroll
         for (int lv = 0; lv < NL; lv++) {
             const uint32_t k_own = ((uint32_t)lv * 2u + comp) * (uint32_t)(N * 8), k_oth = ((uint32_t)lv * 2u + (comp ^ 1u)) * (uint32_t)(N * 8);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
         // key words of this step: this thread's four evaluations of the 2 NL polynomials of its component's rows.  Requested
         // now, used after the forward transforms: a step's 96 KB come out of L2 while the transforms run.
         // (FBS_CU_PREFETCH: requested during the step BEFORE instead, behind its hand-over barrier)
-        const KeyRows keys(a.bsk_hat + ((size_t)i * rows + comp * NL) * 2 * N);   // (buffer loads: fbs_blind_rotate.hpp)
+        const KeyRows keys(a.bsk_hat + ((size_t)FBS_KEY_STEP(i) * rows + comp * NL) * 2 * N);   // (buffer loads: fbs_blind_rotate.hpp)
         if constexpr (!PREFETCH) request_keys(i);
 
         // ---- (X^r - 1) * ACC_c, centred, rounded to the closest multiple of q / B^l; packed balanced digits -------------
@@ -354,6 +354,10 @@ __global__ __launch_bounds__(512, LEAN ? 4 : FBS_CU_WAVES_PER_EU) void k_blind_r
 // (k_blind_rotate_cu_k2, fbs_blind_rotate_k2.hip, has the measurements of this order at k = 2, where it is worth 15 %).  Here, per
 // launch of 64 / 256 bootstraps (tools/cu_latency.py, one box): one level (128-bit p = 15 set, n = 714) 2.63 / 2.90 -> 2.56 / 2.82 ms;
 // two levels (p = 31, n = 766) 4.10 / 4.40 -> 4.15 / 4.46 ms and 16.53 -> 16.73 per 1 024 -- so it is on for one level only.
+// FBS_CU_PAIRS_L2_AHEAD: steps ahead at which the workgroups of an XCD touch the key row (below); 0 = nobody does
+#ifndef FBS_CU_PAIRS_L2_AHEAD
+#define FBS_CU_PAIRS_L2_AHEAD 2
+#endif
 #ifndef FBS_CU_PAIRS_PREFETCH
 #define FBS_CU_PAIRS_PREFETCH 1
 #endif
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
     // (the key words of one register pair (2j, 2j + 1) of a step: three samples x NL rows, of the own or of the partner's column)
     auto request_at = [&](uint32_t step, auto jc, auto partner, double2 (&k)[3][NL]) {
         constexpr int j = decltype(jc)::value;
-        const KeyRows keys(a.bsk_hat + (size_t)step * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N);   // (buffer loads: fbs_blind_rotate.hpp)
+        const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(step) * (3u * rows * 2u) * N + (size_t)comp * (NL * 2u) * N);   // (buffer loads: fbs_blind_rotate.hpp)
         const uint32_t col = decltype(partner)::value ? comp ^ 1u : comp;
 #pragma unroll
         for (int jj = 0; jj < 3; jj++)
@@ -439,6 +443,29 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         request_at(0, Pair0{}, Own{}, ko);
         request_at(0, Pair0{}, Oth{}, kt);
     }
+#if FBS_CU_PAIRS_L2_AHEAD
+    // A step's key row comes out of L2 -- if somebody has brought it there: the key (150 MB at the p = 31 set) lives in the Infinity
+    // Cache / HBM, and the first CU of an XCD to ask for a line waits for the fabric, with every wave of the CU behind the same words.
+    // With every step reading the rows of steps 0 and 1 (-DFBS_EXP_HOT_KEYS, wrong results, a timing experiment) a launch of 1 024 at
+    // that set takes 15.92 ms against 16.58, of 64 3.94 against 4.10; the throughput shapes (three or two waves per SIMD and four
+    // bootstraps per CU asking together) lose nothing there (profiles/r04/hot_keys_l2_ahead.txt).  So the workgroups of an XCD
+    // (blockIdx mod 8), which walk the key in step, each touch ONE line in every `peers` of the row FBS_CU_PAIRS_L2_AHEAD steps
+    // ahead, behind the hand-over barrier when the step's own key words are all in: one load per thread of the first waves, its
+    // value never looked at.  Measured, same box, twice: p = 31 16.65-16.70 -> 16.36-16.45 ms per 1 024, 4.08-4.10 -> 3.93-3.95 per
+    // 64; p = 15 at k = 1 2.48-2.49 -> 2.41-2.42 per 64 (one step ahead: the same within 0.3 %).
+    // (The load is written without a branch -- a thread without a line asks beyond the end of the resource, which touches no memory:
+    // with `if (mine) load` the compiler's schedule of the whole step changed, 196 -> 256 registers and 250 bytes spilled.)
+    // Measured with it and NOT adopted (NL = 2): pairs 0 AND 1 of the key words asked for at the top of the step, two sets of
+    // registers (246, nothing spilled), so that half the row streams in behind the forward transform: 16.88-16.90 against
+    // 16.65-16.70 ms per 1 024, 4.16-4.17 against 4.08-4.10 per 64.  The phase trace agrees that the products are no longer what
+    // waits: 2.4 M cycles per rotation for 2.0 M cycles of instructions, alone on the SIMD or not (profiles/r04/cu_pairs_p31_phase_trace.txt).
+    constexpr uint32_t ROW_LINES = 3u * rows * 2u * N * 8u / 128u;
+    const uint32_t peers = (uint32_t)std::min<size_t>(32, (a.count + 7) / 8);
+    const uint32_t slice_lines = std::min<uint32_t>(512u, (ROW_LINES + peers - 1) / peers);
+    const uint32_t ahead_line = ((blockIdx.x >> 3) % peers) * slice_lines + threadIdx.x;
+    const uint32_t ahead_off = threadIdx.x < slice_lines && ahead_line < ROW_LINES ? ahead_line * 128u : 0x7FFFFFF0u;
+    uint32_t ahead_word = 0;
+#endif
     FBS_TRACE_INIT
     for (uint32_t i = 0; i < n_pairs; i++) {
         uint32_t e[3];
@@ -605,6 +632,14 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         FBS_TRACE(4)
         __syncthreads();
         FBS_TRACE(5)
+#if FBS_CU_PAIRS_L2_AHEAD
+        {   // (no branch: a thread without a line asks beyond the resource's end, which touches no memory)
+            const uint32_t far_step = i + FBS_CU_PAIRS_L2_AHEAD < n_pairs ? i + FBS_CU_PAIRS_L2_AHEAD : n_pairs - 1;
+            const __amdgpu_buffer_rsrc_t far = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double *>(a.bsk_hat + (size_t)far_step * (3u * rows * 2u) * N), 0, ROW_LINES * 128u, 0x00020000);
+            ahead_word = __builtin_amdgcn_raw_buffer_load_b32(far, ahead_off, 0, 0);
+        }
+#endif
 #pragma unroll
         for (int m = 0; m < E; m++) own[m] += hand_mine[64u * m + ln];
         if constexpr (PAIRS_PREFETCH) {
@@ -652,6 +687,9 @@ __global__ __launch_bounds__(512, 2) void k_blind_rotate_cu_pairs(BrArgs a) {
         FBS_TRACE(8)
     }
     FBS_TRACE_FLUSH
+#if FBS_CU_PAIRS_L2_AHEAD
+    asm volatile("" ::"v"(ahead_word));   // (never looked at; this keeps the loads)
+#endif
 
     if (!live) return;
     if (uint64_t *raw = gate_acc(a.gv, f, 2 * N)) {

@@ -19,7 +19,16 @@
 // and 166 registers each would allow it) -- 9.5 against 7.2 ms per 1 024; the next step's first register pair of key words requested behind the read-back, as the
 // twelve-wave shape below does -- 168 registers with 160 bytes spilled instead of 12: 7.60 against 7.21 ms per 1 024; and the
 // monomial factors as psi^(e o_lane) (ONE gather per exponent) times the wave-uniform psi^(e c_m) read through the scalar cache, in
-// the place of a gather from the table in LDS per register pair and exponent: 7.40 against 7.24 ms, same box, twice.)
+// the place of a gather from the table in LDS per register pair and exponent: 7.40 against 7.24 ms, same box, twice.
+// And the three waves of ONE bootstrap meeting on a counter in LDS (release, ds_add, spin with s_sleep, acquire) in the place of the
+// workgroup's s_barrier, so that a bootstrap's waits are filled by the other three: 9.47 against 7.25 ms per 1 024, 18.7 against 14.4
+// per 2 048 -- the same loss as the two six-wave workgroups.  What both give up is the LOCK STEP of the four bootstraps of a CU: they
+// stream the same 221 KB of key words per step, and only while they ask for them together does one of them pull a line out of L2 and
+// the other three find it in the CU's 32 KB of L1.  profiles/r04/k2_boot_meet_ab.txt.
+// Issue priority by turns among the three waves of a SIMD (s_setprio 2 / 1 / 0 or 2 / 0 / 0, rotated every step or every half
+// step -- what gives the benchmark kernel's TWO waves per SIMD 10 %): 7.28-7.36 against 7.30 ms per 1 024, nothing either way
+// (profiles/r04/k2_turns_ab.txt); and with every step reading the same two key rows (-DFBS_EXP_HOT_KEYS) 7.18 against 7.18: no
+// key word is waited for from beyond L2 (profiles/r04/hot_keys_l2_ahead.txt).)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(192 * FPW) void k_blind_rotate_pairs_k2(BrArgs a) {
 
         // ---- bundle x digits, register pair by register pair, added into the three components' buffers ----------------
         // row `comp` of the three samples of step i: [sample][row][column][N]; column c' = the products for component c'
-        const KeyRows keys(a.bsk_hat + ((size_t)i * 3 * K1 + comp) * K1 * N);
+        const KeyRows keys(a.bsk_hat + ((size_t)FBS_KEY_STEP(i) * 3 * K1 + comp) * K1 * N);
 #pragma unroll
         for (int j = 0; j < E / 2; j++) {
             double2 kw[3][K1];
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(768) void k_blind_rotate_cu_k2(BrArgs a) {
     const uint32_t col_bytes[K1] = {comp * (uint32_t)(N * 8), c1 * (uint32_t)(N * 8), c2 * (uint32_t)(N * 8)};
     auto request = [&](uint32_t step, auto jc, double2 (&k)[3][K1]) {
         constexpr int j = decltype(jc)::value;
-        const KeyRows keys(a.bsk_hat + ((size_t)step * 3 * K1 + comp) * K1 * N);
+        const KeyRows keys(a.bsk_hat + ((size_t)FBS_KEY_STEP(step) * 3 * K1 + comp) * K1 * N);
 #pragma unroll
         for (int jj = 0; jj < 3; jj++)
 #pragma unroll
