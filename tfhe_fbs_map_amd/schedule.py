@@ -80,8 +80,8 @@ LAUNCH_FAMILIES = {
                                   (1024, 7.39)), round_ms=7.3, full_from=769),
     "n2048": dict(steps=357, stairs=((1, 2.52), (128, 2.59), (256, 2.86), (257, 4.69), (512, 4.86), (513, 7.8), (768, 7.4), (769, 9.66), (1024, 9.34)),
                   round_ms=9.0, full_from=769),
-    "n2048_l2": dict(steps=383, stairs=((1, 4.16), (128, 4.18), (256, 4.44), (257, 9.0), (512, 8.5), (513, 13.7), (768, 12.5), (769, 17.8), (1024, 16.66)),
-                     round_ms=16.6, full_from=769),
+    "n2048_l2": dict(steps=383, stairs=((1, 4.10), (128, 4.06), (256, 4.41), (257, 9.0), (512, 8.23), (513, 13.6), (768, 12.2), (769, 18.2), (1024, 16.34)),
+                     round_ms=16.2, full_from=769),
 }
 
 
