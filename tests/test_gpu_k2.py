@@ -161,11 +161,21 @@ def test_program_ciphertexts_bit_exact_at_k2(nat, name, T):
     ctx.close()
 
 
-def test_unsupported_k2_shapes_are_refused(nat):
+def test_other_k2_shapes_take_the_general_kernel_or_are_refused(nat):
+    """k = 2 at N = 1024 with one key bit per step or two levels, k = 3: k_blind_rotate_glwe (tests/test_gpu_glwe.py); N = 2048 at
+    k = 2: no kernel, an error code at context creation."""
     from tfhe_fbs_map_amd import FbsError
-    for kw in (dict(log_n_poly=11), dict(bsk_group=1), dict(l_bsk=2, beta_bsk=10), dict(k=3)):
-        with pytest.raises(FbsError):
-            nat.Context(toy(**kw), seed=1)
+    with pytest.raises(FbsError):
+        nat.Context(toy(log_n_poly=11), seed=1)
+    for kw in (dict(bsk_group=1), dict(l_bsk=2, beta_bsk=10), dict(k=3)):
+        ctx, o = nat.Context(toy(**kw), seed=1), orc.Oracle(toy(**kw), seed=1)
+        cts = ctx.encrypt(np.arange(5) % 7, 3)
+        ids = (np.arange(5) % 4).astype(np.uint32)
+        ctx.profile(True)
+        got = ctx.bootstrap_batch(ctx.tvset(TABLES), cts, ids)
+        assert any(k.startswith("k_blind_rotate_glwe<10,") for k in ctx.profile_kernels())
+        assert np.array_equal(got, o.bootstrap_batch(cts, TABLES, ids)[0])
+        ctx.close()
 
 
 def test_eval_takes_k2_at_every_width():

@@ -691,7 +691,20 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     // two-wave form is faster (5.7 against 6.5 ms), beyond two per CU too (9.8-11.1 against 11.1).
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
-    if (p.k == 2) {   // GLWE dimension 2 (N = 1024, two key bits per step, one level: dev_supported admits nothing else)
+    if (p.k >= 2 && !(p.k == 2 && p.log_n_poly == 10 && ctx->group == 2 && p.l_bsk == 1)) {
+        // every (k >= 2, N, l, key bits per step) but the one with kernels of its own: k + 1 waves per bootstrap (fbs_blind_rotate_glwe.hip)
+        a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
+        hipEvent_t c0, c1;
+        prof_begin(ctx, 1, stream, &c0, &c1);
+        if (!launch_blind_rotate_glwe(ctx, a, stream, &ctx->prof.kernel[1])) {
+            if (c0) ctx->prof.pool.push_back({c0, c1});
+            return set_error(ctx, FBS_E_INVALID, "no blind-rotation kernel for this GLWE dimension and polynomial size");
+        }
+        prof_end(ctx, 1, stream, c0, c1);
+        FBS_HIP(ctx, hipGetLastError());
+        return FBS_OK;
+    }
+    if (p.k == 2) {   // GLWE dimension 2 at N = 1024, two key bits per step, one level: the shape the selector picks for p <= 15
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
         // a launch longer than a round of four-bootstrap workgroups whose last round would be (far) from full: whole rounds first,
         // the rest as a launch of its own in the twelve-wave shape (1 124 = 1 024 + 100: 7.3 + 2.1 ms against two rounds' 14.5)
@@ -869,6 +882,7 @@ void blind_rotate_catalog(std::vector<std::string> *out) {
             out->push_back("k_blind_rotate_pairs<" + std::to_string(L) + "," + std::to_string(lanes_log2_for(L)) + "," + std::to_string(dig) + ">");
     blind_rotate_cu_catalog(out);
     blind_rotate_k2_catalog(out);
+    blind_rotate_glwe_catalog(out);
 }
 
 int dev_polymul(fbs_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_c, hipStream_t stream) {

@@ -89,5 +89,9 @@ void blind_rotate_cu_catalog(std::vector<std::string> *out);
 constexpr size_t K2_CU_ROUNDS = 3;   // bootstraps per CU up to which a k = 2 launch takes the twelve-wave shape, round after round
 bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
 void blind_rotate_k2_catalog(std::vector<std::string> *out);
+// fbs_blind_rotate_glwe.hip: every other (k >= 2, N <= 1024, l, key bits per step): k + 1 waves per bootstrap, one wave per polynomial.
+// Returns false when no instantiation is built for the context's (N, k).
+bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
+void blind_rotate_glwe_catalog(std::vector<std::string> *out);
 
 }  // namespace fbs

@@ -229,6 +229,7 @@ void host_twiddles(uint32_t log_n, std::vector<uint64_t> &fwd, std::vector<uint6
 
 // device side (fbs_kernels.hip); all asynchronous on `stream`
 int dev_supported(const fbs_ctx *ctx);   // FBS_OK or error if no kernel instance for the params
+bool glwe_shape_built(uint32_t log_n, uint32_t k);   // fbs_blind_rotate_glwe.hip: is there a kernel for GLWE dimension k >= 2 at N = 2^log_n?
 int dev_upload_keys(fbs_ctx *ctx);       // BSK -> NTT domain, KSK padded
 int dev_keyswitch_gemm_setup(fbs_ctx *ctx);   // limb fragments of the key-switching key for the int8 MFMA key switch
 int dev_keyswitch(fbs_ctx *ctx, const GateView &gv, uint32_t *d_ms, hipStream_t stream);

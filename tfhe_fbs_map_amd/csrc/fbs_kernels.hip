@@ -649,9 +649,9 @@ void prof_end(fbs_ctx *ctx, int which, hipStream_t s, hipEvent_t e0, hipEvent_t 
 
 int dev_supported(const fbs_ctx *ctx) {
     const fbs_params &p = ctx->p;
-    if (p.k == 2 && !(p.log_n_poly == 10 && p.bsk_group == 2 && p.l_bsk == 1))
-        return set_error(ctx, FBS_E_INVALID, "GLWE dimension k = 2 is built for N = 1024 with two key bits per step and one gadget level");
-    if (p.k != 1 && p.k != 2) return set_error(ctx, FBS_E_INVALID, "this build supports GLWE dimensions k = 1 and k = 2 (N = 1024) only");
+    if (p.k >= 2 && !glwe_shape_built(p.log_n_poly, p.k))
+        return set_error(ctx, FBS_E_INVALID, "GLWE dimensions k >= 2 are built for k = 2, 3, 4 at N = 256 and 512 and k = 2, 3 at N = 1024");
+    if (p.k < 1) return set_error(ctx, FBS_E_INVALID, "need k >= 1");
     if (p.log_n_poly < 8 || p.log_n_poly > 12)
         return set_error(ctx, FBS_E_INVALID, "supported polynomial sizes are N = 256, 512, 1024, 2048, 4096");
     if (p.l_bsk < 1 || p.beta_bsk < 1 || p.l_bsk * p.beta_bsk > 30 || p.l_bsk * p.beta_bsk > FQ_BITS - 2)
@@ -659,8 +659,8 @@ int dev_supported(const fbs_ctx *ctx) {
     if (p.t_ksk < 1 || p.gamma_ksk < 1 || p.t_ksk * p.gamma_ksk > 31 || p.t_ksk * p.gamma_ksk > FQ_BITS - 2)
         return set_error(ctx, FBS_E_INVALID, "need 1 <= t*gamma <= 31");
     if (p.n < 1 || p.n > 4096) return set_error(ctx, FBS_E_INVALID, "need 1 <= n <= 4096");
-    if (p.bsk_group == 2 && (p.log_n_poly < 10 || p.l_bsk > 5))
-        return set_error(ctx, FBS_E_INVALID, "two key bits per step (bsk_group = 2) is built for N = 1024, 2048 and 4096, l <= 5");
+    if (p.bsk_group == 2 && p.k == 1 && (p.log_n_poly < 10 || p.l_bsk > 5))
+        return set_error(ctx, FBS_E_INVALID, "two key bits per step (bsk_group = 2) at k = 1 is built for N = 1024, 2048 and 4096, l <= 5");
     // lazy FP64 ranges (fbs_field.hpp): partial external products stay below 2^50 while (k+1)*l <= 20
     if ((p.k + 1) * p.l_bsk > 20) return set_error(ctx, FBS_E_INVALID, "need (k+1)*l <= 20");
     // 64-bit key-switch accumulators: D*t digits < 2^gamma times words < 2^46

@@ -90,7 +90,7 @@ def launch_family(params):
     over the steps of the set the staircase was measured at).  Shapes without a measured staircase of their own take P1024's,
     scaled by the modelled cost of a bootstrap (params.bootstrap_cost)."""
     steps = params.n // 2 if params.bsk_group == 2 else params.n
-    if params.k == 2:
+    if params.k == 2 and params.N == 1024 and params.bsk_group == 2 and params.l_bsk == 1:
         name = "k2"
     elif params.N == 2048 and params.bsk_group == 2 and params.l_bsk <= 2:
         name = "n2048" if params.l_bsk == 1 else "n2048_l2"

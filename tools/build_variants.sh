@@ -6,7 +6,7 @@ cd $(dirname $0)/../tfhe_fbs_map_amd/csrc || exit 1
 mkdir -p ../../gpurun_exp
 SRC=$1; shift
 OBJS=""
-for f in fbs_host.cpp fbs_plan.cpp fbs_capi.cpp fbs_kernels.hip fbs_blind_rotate.hip fbs_blind_rotate_cu.hip fbs_blind_rotate_k2.hip fbs_mapper_search.hip; do
+for f in fbs_host.cpp fbs_plan.cpp fbs_capi.cpp fbs_kernels.hip fbs_blind_rotate.hip fbs_blind_rotate_cu.hip fbs_blind_rotate_k2.hip fbs_blind_rotate_glwe.hip fbs_mapper_search.hip; do
   [ $f = $SRC ] || OBJS="$OBJS build/$f.o"
 done
 while [ $# -ge 2 ]; do

@@ -7,7 +7,7 @@
 cd $(dirname $0)/../tfhe_fbs_map_amd/csrc
 for V in 0 2; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -ffp-contract=off -DFBS_CU_TRACE -DFBS_CU_PRIO=$V -c -o /tmp/cu_trace$V.o fbs_blind_rotate_cu.hip || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o /tmp/libfbsexec_trace$V.so build/fbs_host.cpp.o build/fbs_plan.cpp.o build/fbs_capi.cpp.o build/fbs_kernels.hip.o build/fbs_blind_rotate.hip.o build/fbs_blind_rotate_k2.hip.o /tmp/cu_trace$V.o build/fbs_mapper_search.hip.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o /tmp/libfbsexec_trace$V.so build/fbs_host.cpp.o build/fbs_plan.cpp.o build/fbs_capi.cpp.o build/fbs_kernels.hip.o build/fbs_blind_rotate.hip.o build/fbs_blind_rotate_k2.hip.o build/fbs_blind_rotate_glwe.hip.o /tmp/cu_trace$V.o build/fbs_mapper_search.hip.o || exit 1
 done
 cd ../..
 for V in 0 2; do
