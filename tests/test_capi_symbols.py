@@ -47,7 +47,7 @@ def test_no_cpu_fallback():
 
 def test_bad_parameters_rejected_before_touching_the_device():
     from tfhe_fbs_map_amd import Context, FbsError, Params
-    for bad in (Params(k=2), Params(log_n_poly=13), Params(l_bsk=5, beta_bsk=7), Params(p_msg=0)):
+    for bad in (Params(k=2, log_n_poly=11), Params(k=5, log_n_poly=9), Params(log_n_poly=13), Params(l_bsk=5, beta_bsk=7), Params(p_msg=0)):
         with pytest.raises(FbsError) as e:
             Context(bad)
         assert e.value.code == -1
