@@ -62,10 +62,11 @@ def recipe(name):
                     knobs={} if fpw == 4 else dict(br_k2_shape=3))
     if name == "k_blind_rotate_cu_k2":                    # ... one bootstrap on the twelve waves of a workgroup: two rounds, the second partial
         return dict(log_n=10, l=1, beta=20, group=2, k=2, count=CUS + 41, knobs={})
-    m = re.fullmatch(r"k_blind_rotate_glwe<(\d+),(\d),(\d)>", name)
-    if m:                                                 # every other GLWE dimension / size / depth: k + 1 waves per bootstrap, a ragged last workgroup,
-        L, k1, group = (int(m.group(i)) for i in (1, 2, 3))   # two gadget levels (k = 2 at N = 1024 with one level and two key bits per step has its own kernels)
-        return dict(log_n=L, l=2, beta=8, group=group, k=k1 - 1, count=41, knobs={})
+    m = re.fullmatch(r"k_blind_rotate_glwe<(\d+),(\d),(\d),(\d)>", name)
+    if m:                                                 # every other GLWE dimension / size / depth: k + 1 waves per bootstrap, two gadget levels
+        L, k1, group, fpw = (int(m.group(i)) for i in (1, 2, 3, 4))   # (k = 2 at N = 1024 with one level and two key bits per step has its own kernels);
+        # one bootstrap per workgroup up to one per CU, two up to two, the throughput shape beyond: a ragged last workgroup each time
+        return dict(log_n=L, l=2, beta=8, group=group, k=k1 - 1, count={1: 41, 2: CUS + 41}.get(fpw, 2 * CUS + 41), knobs={})
     m = re.fullmatch(r"k_blind_rotate_cu<(\d+),(\d+),(\d+)(,lean)?>", name)
     if m:
         L, nl, first = int(m.group(1)), int(m.group(2)), int(m.group(3))
@@ -127,7 +128,7 @@ def run_case(name, rec):
 def test_every_catalog_entry_has_a_recipe():
     missing = [k for k in catalog() if recipe(k) is None]
     assert not missing, missing
-    assert len(set(catalog())) == len(catalog()) >= 106
+    assert len(set(catalog())) == len(catalog()) >= 160
 
 
 def test_instantiation_against_the_oracle(kernel_name):

@@ -40,7 +40,7 @@ def test_ragged_batches_bit_exact(nat, log_n, k, l, beta, group):
     prm = toy(log_n_poly=log_n, k=k, l_bsk=l, beta_bsk=beta, bsk_group=group)
     ctx, o = nat.Context(prm, seed=4), orc.Oracle(prm, seed=4)
     tv = ctx.tvset(TABLES)
-    want = "k_blind_rotate_glwe<%d,%d,%d>" % (log_n, k + 1, group)
+    want = "k_blind_rotate_glwe<%d,%d,%d,1>" % (log_n, k + 1, group)       # (up to one bootstrap per CU: one per workgroup)
     for B in (1, 2, 3, 5, 13, 70):
         msgs = np.arange(B) % 7
         ids = (np.arange(B) % 4).astype(np.uint32)
@@ -60,19 +60,41 @@ def test_ragged_batches_bit_exact(nat, log_n, k, l, beta, group):
     ctx.close()
 
 
-def test_a_launch_longer_than_the_chip(nat):
-    """2 100 bootstraps at k = 3, N = 512: several rounds of workgroups, the oracle on both ends and a spread."""
-    prm = toy()
+@pytest.mark.parametrize("k, group", [(3, 2), (2, 1)])
+def test_launch_shapes_by_size_and_the_cut(nat, k, group):
+    """N = 512: one bootstrap per workgroup up to one per CU, two up to two, the throughput shape (three at k = 3, four at k = 2) beyond;
+    a launch longer than a round of the throughput shape whose rest is small is CUT -- whole rounds, then the rest in the small shape.
+    Each size against the oracle on both ends, either side of the cut and a spread; then the same sizes with one shape forced."""
+    prm = toy(k=k, bsk_group=group, l_bsk=1, beta_bsk=18)
     ctx, o = nat.Context(prm, seed=9), orc.Oracle(prm, seed=9)
-    B = 2100
+    cus, full = ctx.stat("cu_count"), 12 // (k + 1)
+    name = lambda fpw: "k_blind_rotate_glwe<9,%d,%d,%d>" % (k + 1, group, fpw)
     rng = np.random.default_rng(3)
+    tv = ctx.tvset(TABLES)
+    cases = [(cus - 3, [name(1)]), (2 * cus - 5, [name(2)]), (full * cus - 7, [name(full)]), (full * cus + 100, [name(full), name(1)]),
+             (full * cus + 2 * cus - 1, [name(full), name(2)]), (2 * full * cus + 2 * cus + 9, [name(full)])]
+    for B, want in cases:
+        ids = rng.integers(0, 4, B).astype(np.uint32)
+        msgs = np.array([rng.integers(0, len(TABLES[i])) for i in ids])
+        cts = ctx.encrypt(msgs, nonce0=11)
+        cts[B - 1, :-1] = 0
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        got = ctx.bootstrap_batch(tv, cts, ids)
+        assert sorted(k_ for k_ in ctx.profile_kernels() if "blind_rotate" in k_) == sorted(want), (B, ctx.profile_kernels())
+        edge = full * cus * (B // (full * cus))
+        pick = np.unique(np.clip(np.concatenate([np.arange(6), np.arange(B - 6, B), np.arange(edge - 4, edge + 4), rng.integers(0, B, 8)]), 0, B - 1))
+        ref, _ = o.bootstrap_batch(cts[pick], TABLES, ids[pick])
+        assert np.array_equal(got[pick], ref), B
+    B = 2 * cus + 9
     ids = rng.integers(0, 4, B).astype(np.uint32)
-    msgs = np.array([rng.integers(0, len(TABLES[i])) for i in ids])
-    cts = ctx.encrypt(msgs, nonce0=11)
-    got = ctx.bootstrap_batch(ctx.tvset(TABLES), cts, ids)
-    pick = np.unique(np.concatenate([np.arange(6), np.arange(B - 6, B), rng.integers(0, B, 12)]))
-    ref, _ = o.bootstrap_batch(cts[pick], TABLES, ids[pick])
-    assert np.array_equal(got[pick], ref)
+    cts = ctx.encrypt(np.array([rng.integers(0, len(TABLES[i])) for i in ids]), nonce0=77)
+    auto = ctx.bootstrap_batch(tv, cts, ids)
+    for fpw in (1, 2, full):
+        ctx.tune(br_glwe_fpw=fpw)
+        ctx.profile_read(reset=True)
+        assert np.array_equal(ctx.bootstrap_batch(tv, cts, ids), auto)          # the same ciphertexts whatever the shape
+        assert name(fpw) in ctx.profile_kernels()
     ctx.close()
 
 

@@ -692,17 +692,36 @@ int dev_blind_rotate(fbs_ctx *ctx, const fbs_tvset *tv, const GateView &gv, cons
     const bool pair = lanes_log2_for((int)p.log_n_poly) == 6 && count > (size_t)ctx->cu_count && count <= 2 * (size_t)ctx->cu_count;
     dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
     if (p.k >= 2 && !(p.k == 2 && p.log_n_poly == 10 && ctx->group == 2 && p.l_bsk == 1)) {
-        // every (k >= 2, N, l, key bits per step) but the one with kernels of its own: k + 1 waves per bootstrap (fbs_blind_rotate_glwe.hip)
+        // every (k >= 2, N, l, key bits per step) but the one with kernels of its own: k + 1 waves per bootstrap (fbs_blind_rotate_glwe.hip).
+        // Bootstraps per workgroup by launch size: one up to one bootstrap per CU, two up to two, the throughput shape beyond; a launch
+        // longer than a round of the throughput shape whose last round would be at most two bootstraps per CU: whole rounds first, the
+        // rest as a launch of its own (k = 3, N = 512: 1 024 = 768 + 256 bootstraps in 4.1 + 1.8 ms against two rounds' 7.4)
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);
+        const size_t cus = (size_t)ctx->cu_count;
+        const int full = glwe_full_fpw(p.log_n_poly, p.k);
+        const size_t per_round = (size_t)full * cus, rest_n = per_round ? count % per_round : 0;
+        const bool small_ok = ctx->tune.br_cu_max_per_cu >= 1 && ctx->tune.br_glwe_fpw == 0;
+        const bool cut = small_ok && ctx->tune.br_whole_cu && count > per_round && rest_n != 0 && rest_n <= (full > 2 ? 2 : 1) * cus;
+        if (cut) {
+            a.count = count - rest_n;
+            a.gv.count = a.count;
+        }
+        int fpw = (int)ctx->tune.br_glwe_fpw;
+        if (fpw == 0) fpw = !small_ok ? full : a.count <= cus ? 1 : (a.count <= 2 * cus && full > 2) ? 2 : full;
         hipEvent_t c0, c1;
         prof_begin(ctx, 1, stream, &c0, &c1);
-        if (!launch_blind_rotate_glwe(ctx, a, stream, &ctx->prof.kernel[1])) {
+        if (!launch_blind_rotate_glwe(ctx, a, fpw, stream, &ctx->prof.kernel[1])) {
             if (c0) ctx->prof.pool.push_back({c0, c1});
             return set_error(ctx, FBS_E_INVALID, "no blind-rotation kernel for this GLWE dimension and polynomial size");
         }
         prof_end(ctx, 1, stream, c0, c1);
         FBS_HIP(ctx, hipGetLastError());
-        return FBS_OK;
+        if (!cut) return FBS_OK;
+        GateView rest = gv;
+        rest.f_begin += count - rest_n;
+        rest.count = rest_n;
+        if (rest.out_rows) rest.out_rows += (count - rest_n) * (size_t)(rest.row_words ? rest.row_words : ctx->D + 1);
+        return dev_blind_rotate(ctx, tv, rest, d_ms, stream);
     }
     if (p.k == 2) {   // GLWE dimension 2 at N = 1024, two key bits per step, one level: the shape the selector picks for p <= 15
         a.psi_pow = reinterpret_cast<const double *>(ctx->d_psi_pow);

@@ -91,7 +91,9 @@ bool launch_blind_rotate_k2(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, s
 void blind_rotate_k2_catalog(std::vector<std::string> *out);
 // fbs_blind_rotate_glwe.hip: every other (k >= 2, N <= 1024, l, key bits per step): k + 1 waves per bootstrap, one wave per polynomial.
 // Returns false when no instantiation is built for the context's (N, k).
-bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel);
+// fpw: bootstraps per workgroup -- 1, 2, or anything else for the throughput shape (glwe_full_fpw of them)
+bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, int fpw, hipStream_t stream, std::string *kernel);
+int glwe_full_fpw(uint32_t log_n, uint32_t k);
 void blind_rotate_glwe_catalog(std::vector<std::string> *out);
 
 }  // namespace fbs

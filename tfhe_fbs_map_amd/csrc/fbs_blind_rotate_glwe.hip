@@ -9,13 +9,13 @@
 // workgroup barrier inside them); FPW bootstraps share a workgroup, its twiddle tables and -- walking the key in lock step -- the key
 // lines in L1.  A step, per wave:
 //   one key bit per step:  (X^r - 1) ACC_c through the wave's own LDS words (rotated read), rounded; two key bits: ACC_c itself
-//   per gadget level:      balanced digit -> forward transform -> products with key row (c, level) for ALL k + 1 output components,
-//                          summed over the levels in registers (two key bits: the key word is the bundle
-//                          sum_jj (zeta^e_jj - 1) E_jj, zeta = the evaluation point the register holds)
-//   hand-over:             the wave clears its own buffer; barrier; every wave ADDS its products for the k other components into
-//                          their buffers (ds_add_f64: exact on integer-valued doubles below 2^53, so the order does not matter);
-//                          barrier; own products + what landed -> inverse transform -> accumulate.
-// Two workgroup barriers per step.  The columns of a key row are taken in ROTATED order (d = 0 .. k stands for component
+//   per gadget level:      balanced digit -> forward transform -> products with key row (c, level) for ALL k + 1 output components
+//                          (two key bits: the key word is the bundle sum_jj (zeta^e_jj - 1) E_jj, zeta = the evaluation point the
+//                          register holds)
+//   hand-over:             the products for the k other components are ADDED into those components' landing words as they are made
+//                          (ds_add_f64: exact on integer-valued doubles below 2^53, so the order does not matter); barrier; own
+//                          products + what landed -> landing words cleared -> inverse transform -> accumulate.
+// ONE workgroup barrier per step where LDS holds two sets of landing words taken in turns (N <= 512), two where it holds one.  The columns of a key row are taken in ROTATED order (d = 0 .. k stands for component
 // c + d mod k + 1), so that "which product goes where" is the same code in every wave and no register array is indexed by a
 // run-time value.  Same rounding rules and, word for word, the same ciphertexts as the oracle (tests/test_gpu_glwe.py).
 #include <hip/hip_runtime.h>
@@ -26,6 +26,18 @@
 #include <vector>
 
 #include "fbs_blind_rotate.hpp"
+
+// chunks of key words in flight beyond the one being multiplied (measured at k = 3, N = 512, n = 614, ms per 1 536 bootstraps:
+// 1: 7.28, 2: 7.54 (64-148 bytes spilled at the 168 registers of three waves per SIMD), 3: 9.62; k = 3 at N = 1024: 16.8 / 17.7 / 18.9)
+#ifndef FBS_GLWE_CHUNKS_AHEAD
+#define FBS_GLWE_CHUNKS_AHEAD 1
+#endif
+#ifndef FBS_GLWE_L2_AHEAD
+#define FBS_GLWE_L2_AHEAD 2
+#endif
+#ifndef FBS_GLWE_DEAL
+#define FBS_GLWE_DEAL 1
+#endif
 
 namespace fbs {
 
@@ -48,24 +60,34 @@ template <int LOGN, int K1, int GROUP, int FPW>
 __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
     using W = typename NttFor<LOGN, 6>::type;
     using Pos = EvalPosition<W, LOGN>;
-    constexpr int N = W::N, E = W::E, LANES = W::LANES;
+    constexpr int N = W::N, E = W::E, LANES = W::LANES, WAVES = FPW * K1, NS = GROUP == 2 ? 3 : 1;   // NS: GGSW samples per step
     static_assert(LANES == 64 && (E == 4 || E == 8 || E == 16), "one wave per polynomial");
-    // [wave][N] exchange buffers (wave = K1 * bootstrap + component) = landing words of the hand-over; forward and inverse per-lane
+    // LANDING words of the hand-over, one set per wave beside its exchange buffer: TWO sets taken in turns where LDS has the room
+    // (then a set is cleared by its owner a whole step before anybody adds into it again, and ONE barrier per step is enough)
+    constexpr int SETS = (size_t)(3 * WAVES + 3) * N * 8 <= 160 * 1024 ? 2 : 1;
+    // [wave][N] exchange buffers (wave = K1 * bootstrap + component); [set][wave][N] landing words; forward and inverse per-lane
     // twiddle tables; psi^x, x < N (two key bits per step)
-    __shared__ __attribute__((aligned(16))) double lds_all[FPW * K1 * N + 2 * N + (GROUP == 2 ? N : 0)];
+    __shared__ __attribute__((aligned(16))) double lds_all[(1 + SETS) * WAVES * N + 2 * N + (GROUP == 2 ? N : 0)];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t sub = wave / (uint32_t)K1, comp = wave - (uint32_t)K1 * sub;   // bootstrap of the workgroup, GLWE component
+    // bootstrap of the workgroup, GLWE component.  The waves of a workgroup are dealt round the four SIMDs, and the waves that hold
+    // the SAME component of different bootstraps ask for the same key words: they must sit on DIFFERENT SIMDs to run side by side and
+    // find each other's lines in L1 -- with four components wave w and w + 4 would share a SIMD, so bootstrap s takes its components
+    // rotated by s (measured at k = 3, N = 512, n = 570: FBS_GLWE_DEAL below)
+    const uint32_t sub = wave / (uint32_t)K1, in_sub = wave - (uint32_t)K1 * sub;
+    const uint32_t comp = (K1 % 4 == 0 && FBS_GLWE_DEAL) ? (in_sub + sub) % (uint32_t)K1 : in_sub;
     const uint32_t t = threadIdx.x & 63u;
     double *mine = lds_all + wave * N;
-    double *tables = lds_all + FPW * K1 * N;
+    double *landing = lds_all + WAVES * N;
+    double *tables = lds_all + (1 + SETS) * WAVES * N;
     typename W::Xchg xc{mine, 0};
     xc.stride = 0;
     Twiddles twf(tables, a.tw_fwd), twi(tables + N, a.tw_inv);
-    for (uint32_t x = threadIdx.x; x < (uint32_t)N; x += 64u * K1 * FPW) {
+    for (uint32_t x = threadIdx.x; x < (uint32_t)N; x += 64u * WAVES) {
         tables[x] = a.tw_fwd[W::LANE_TABLE_OFFSET + x];
         tables[N + x] = a.tw_inv[W::LANE_TABLE_OFFSET + x];
         if constexpr (GROUP == 2) tables[2 * N + x] = a.psi_pow[x];
     }
+    for (uint32_t x = threadIdx.x; x < (uint32_t)(SETS * WAVES * N); x += 64u * WAVES) landing[x] = 0.0;
     __syncthreads();
 
     // a workgroup past the end of a batch that is not a multiple of FPW repeats the last bootstrap (its waves must keep meeting
@@ -101,13 +123,12 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
         sign_bits |= bhalf << (j * a.beta);
     }
     // the components in rotated order: d stands for component comp + d (mod K1); d = 0 is this wave's own
-    uint32_t col_bytes[K1];
-    double *land[K1];
+    uint32_t col_bytes[K1], land_word[K1];
 #pragma unroll
     for (int d = 0; d < K1; d++) {
         const uint32_t c = comp + (uint32_t)d >= (uint32_t)K1 ? comp + (uint32_t)d - (uint32_t)K1 : comp + (uint32_t)d;
         col_bytes[d] = c * (uint32_t)(N * 8);
-        land[d] = lds_all + (sub * (uint32_t)K1 + c) * N;
+        land_word[d] = (sub * (uint32_t)K1 + c) * (uint32_t)N;
     }
     const uint32_t rows = (uint32_t)K1 * a.l;                       // rows of a GGSW sample
     const uint32_t t16 = t * 16u;                                   // this thread's 16 bytes of a register pair's 64 lanes
@@ -116,6 +137,18 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
 
     constexpr uint32_t STEP_BITS = GROUP;
     const uint32_t n_steps = a.n / STEP_BITS;
+    // The key rows of a step come out of L2 if somebody has brought them there (the key lives in the Infinity Cache / HBM; with every
+    // step reading the rows of steps 0 and 1 -- -DFBS_EXP_HOT_KEYS, a timing experiment -- k = 3 at N = 512 takes 4.62 ms per 768
+    // against 5.55, at N = 1024 15.3 against 25.1).  As in k_blind_rotate_cu_pairs: the workgroups of an XCD (blockIdx mod 8), which
+    // walk the key in step, each touch one line in every `peers` of the rows FBS_GLWE_L2_AHEAD steps ahead, behind the step's barrier
+    // -- one load per thread, branch-free (a thread without a line asks beyond the end of the resource), its value never looked at.
+    const uint32_t row_lines = (GROUP == 2 ? 3u : 1u) * rows * (uint32_t)K1 * (uint32_t)(N * 8 / 128);
+    const uint32_t n_groups = (uint32_t)((a.count + FPW - 1) / FPW);
+    const uint32_t peers = std::min<uint32_t>(32u, (n_groups + 7u) / 8u);
+    const uint32_t slice_lines = std::min<uint32_t>(64u * WAVES, (row_lines + peers - 1u) / peers);
+    const uint32_t ahead_line = ((blockIdx.x >> 3) % peers) * slice_lines + threadIdx.x;
+    const uint32_t ahead_off = threadIdx.x < slice_lines && ahead_line < row_lines ? ahead_line * 128u : 0x7FFFFFF0u;
+    uint32_t ahead_word = 0;
     uint32_t e0_next = ms[0], e1_next = GROUP == 2 ? ms[1] : 0u;
     for (uint32_t i = 0; i < n_steps; i++) {
         uint32_t e[3];
@@ -124,9 +157,10 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
         // (ms has n + 1 entries: the last step reads the body word, or re-reads it, and ignores it)
         e0_next = ms[STEP_BITS * (i + 1) < a.n ? STEP_BITS * (i + 1) : a.n];
         if constexpr (GROUP == 2) e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
-        if (e[0] == 0 && e[1] == 0) {   // nothing to add for this bootstrap: the others of the workgroup still meet their two barriers
+        double *land = landing + (SETS == 2 ? (i & 1u) * (uint32_t)(WAVES * N) : 0u);   // this step's set of landing words
+        if (e[0] == 0 && e[1] == 0) {   // nothing to add for this bootstrap: the others of the workgroup still meet their barriers
             if constexpr (FPW > 1) {
-                __syncthreads();
+                if constexpr (SETS == 1) __syncthreads();
                 __syncthreads();
             }
             continue;
@@ -153,95 +187,129 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
 #pragma unroll
             for (int m = 0; m < E; m++) digits[m] = (uint32_t)__builtin_fma(acc[m], round_scale, round_offset) ^ sign_bits;
         }
+        // one set of landing words: everybody has read and cleared its own since the last step's additions
+        if constexpr (SETS == 1) __syncthreads();
 
-        // ---- level by level: digit, forward transform, products for the K1 output components (lazy sums over the levels) ---------
-        double prod[K1][E];
+        // ---- level by level: digit, forward transform, products for the K1 output components: the own one summed in registers, the
+        // others ADDED into those components' landing words as they are made (ds_add_f64: exact on integer-valued doubles below
+        // 2^53 -- (k + 1) l products below 0.8 q each -- so the order in which they land does not matter) ---------------------------
+        double own[E];
 #pragma unroll
-        for (int d = 0; d < K1; d++)
-#pragma unroll
-            for (int m = 0; m < E; m++) prod[d][m] = 0.0;
+        for (int m = 0; m < E; m++) own[m] = 0.0;
         for (int lv = (int)a.l - 1; lv >= 0; lv--) {
             const uint32_t shift = (a.l - 1u - (uint32_t)lv) * a.beta;
             double x[E];
 #pragma unroll
             for (int m = 0; m < E; m++) x[m] = (double)(int)__builtin_amdgcn_sbfe(digits[m], shift, a.beta);   // balanced digit in [-B/2, B/2)
-            W::template forward<0>(x, xc, t, twf, typename W::NoHook{});
             const uint32_t row_bytes = ((comp * a.l + (uint32_t)lv) * (uint32_t)K1) * (uint32_t)(N * 8);
-            if constexpr (GROUP == 1) {
-                // row (comp, lv) of the sample of step i: [row][column][N]
-                const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(i) * rows * K1 * N);
+            // row (comp, lv) of the sample(s) of step i: [sample][row][column][N] (one sample with one key bit per step, three with two)
+            const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(i) * NS * rows * K1 * N);
+            const uint32_t sample_bytes = rows * (uint32_t)K1 * (uint32_t)(N * 8);
+            // The work of a level after its transform comes in CHUNKS (register pair j, column d): the key words of the chunk -- one per
+            // sample -- times the pair's evaluations, for component comp + d.  The compiler keeps a buffer load behind every LDS atomic
+            // written before it (it cannot tell the two apart), so written chunk by chunk -- load, multiply, add -- every load would wait
+            // for its own round trip with nothing else in flight (the first form of this kernel: s_waitcnt vmcnt(0) behind each of the
+            // 48 loads of a step; k = 3 at N = 512, n = 614: 8.9 ms per 1 536 bootstraps against 7.3 now).  Here the words of chunk c + AHEAD are asked for
+            // BEFORE chunk c is multiplied, and the products of chunk c land while chunk c + 1 is multiplied: a chunk's words have AHEAD
+            // chunks of arithmetic to arrive in.  The first chunks of a level are asked for ahead of its transform.
+            constexpr int CHUNKS = (E / 2) * K1, AHEAD = FBS_GLWE_CHUNKS_AHEAD < CHUNKS ? FBS_GLWE_CHUNKS_AHEAD : CHUNKS - 1, BUFS = AHEAD + 1;
+            double2 kbuf[BUFS][NS];
+            auto request = [&](int c, double2 (&k)[NS]) {
+                const int j = c / K1, d = c % K1;
 #pragma unroll
-                for (int j = 0; j < E / 2; j++) {
-                    double2 kw[K1];
+                for (int jj = 0; jj < NS; jj++)
+                    k[jj] = keys.load(t16 + (uint32_t)(j * LANES * 16), (uint32_t)jj * sample_bytes + row_bytes + col_bytes[d]);
+            };
 #pragma unroll
-                    for (int d = 0; d < K1; d++) kw[d] = keys.load(t16 + (uint32_t)(j * LANES * 16), row_bytes + col_bytes[d]);
+            for (int c = 0; c < AHEAD; c++) request(c, kbuf[c % BUFS]);
+            W::template forward<0>(x, xc, t, twf, typename W::NoHook{});
+            double mono[3][2];
+            double late0 = 0.0, late1 = 0.0;   // the products of the chunk before, not landed yet
 #pragma unroll
-                    for (int d = 0; d < K1; d++) {
-                        const double p0 = fp_mulmod(x[2 * j], kw[d].x), p1 = fp_mulmod(x[2 * j + 1], kw[d].y);
-                        prod[d][2 * j] += p0;
-                        prod[d][2 * j + 1] += p1;
-                    }
-                }
-            } else {
-                // the three samples of step i: [sample][row][column][N]
-                const KeyRows keys(a.bsk_hat + (size_t)FBS_KEY_STEP(i) * 3 * rows * K1 * N);
-                const uint32_t sample_bytes = rows * (uint32_t)K1 * (uint32_t)(N * 8);
-#pragma unroll
-                for (int j = 0; j < E / 2; j++) {
-                    // zeta^e - 1 for the two registers of the pair and the three exponents: zeta = psi^(o_lane + c_m), psi^(x + N) = -psi^x
-                    double mono[3][2];
-#pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const uint32_t o = o_lane + Pos::exponent(Pos::reg(2 * j + r));
+            for (int c = 0; c < CHUNKS; c++) {
+                const int j = c / K1, d = c % K1;
+                if (c + AHEAD < CHUNKS) request(c + AHEAD, kbuf[(c + AHEAD) % BUFS]);
+                if constexpr (GROUP == 2) {
+                    if (d == 0) {
+                        // zeta^e - 1 for the two registers of the pair and the three exponents: zeta = psi^(o_lane + c_m), psi^(x + N) = -psi^x;
+                        // where the pair's evaluation points differ by psi^N = -1, one look-up per exponent serves both
+                        const uint32_t c0 = Pos::exponent(Pos::reg(2 * j)), c1 = Pos::exponent(Pos::reg(2 * j + 1));   // (constants once unrolled)
+                        const bool twins = c1 - c0 == (uint32_t)N;
 #pragma unroll
                         for (int jj = 0; jj < 3; jj++) {
-                            const uint32_t xx = (e[jj] * o) & (2u * N - 1u);
+                            const uint32_t xx = (e[jj] * (o_lane + c0)) & (2u * N - 1u);
                             const double v = psi[xx & (N - 1)];
-                            mono[jj][r] = __hiloint2double(__double2hiint(v) ^ (int)((xx << (31 - LOGN)) & 0x80000000u), __double2loint(v)) - 1.0;
+                            const int hi = __double2hiint(v) ^ (int)((xx << (31 - LOGN)) & 0x80000000u);
+                            mono[jj][0] = __hiloint2double(hi, __double2loint(v)) - 1.0;
+                            if (twins) {
+                                mono[jj][1] = __hiloint2double(hi ^ (int)(e[jj] << 31), __double2loint(v)) - 1.0;
+                            } else {
+                                const uint32_t yy = (e[jj] * (o_lane + c1)) & (2u * N - 1u);
+                                const double u = psi[yy & (N - 1)];
+                                mono[jj][1] = __hiloint2double(__double2hiint(u) ^ (int)((yy << (31 - LOGN)) & 0x80000000u), __double2loint(u)) - 1.0;
+                            }
                         }
-                    }
-#pragma unroll
-                    for (int d = 0; d < K1; d++) {
-                        double2 kw[3];
-#pragma unroll
-                        for (int jj = 0; jj < 3; jj++)
-                            kw[jj] = keys.load(t16 + (uint32_t)(j * LANES * 16), (uint32_t)jj * sample_bytes + row_bytes + col_bytes[d]);
-                        // bundle words: lazy sums of three exact products (< 2.4 q); |x| < 2^49.3, so the products below stay exact
-                        double w0 = fp_mulmod(kw[0].x, mono[0][0]), w1 = fp_mulmod(kw[0].y, mono[0][1]);
-#pragma unroll
-                        for (int jj = 1; jj < 3; jj++) {
-                            w0 += fp_mulmod(kw[jj].x, mono[jj][0]);
-                            w1 += fp_mulmod(kw[jj].y, mono[jj][1]);
-                        }
-                        const double p0 = fp_mulmod(x[2 * j], w0), p1 = fp_mulmod(x[2 * j + 1], w1);
-                        prod[d][2 * j] += p0;
-                        prod[d][2 * j + 1] += p1;
                     }
                 }
+                const double2(&kw)[NS] = kbuf[c % BUFS];
+                double w0, w1;
+                if constexpr (GROUP == 1) {
+                    w0 = kw[0].x;
+                    w1 = kw[0].y;
+                } else {
+                    // bundle words: lazy sums of three exact products (< 2.4 q); |x| < 2^49.3, so the products below stay exact
+                    w0 = fp_mulmod(kw[0].x, mono[0][0]);
+                    w1 = fp_mulmod(kw[0].y, mono[0][1]);
+#pragma unroll
+                    for (int jj = 1; jj < 3; jj++) {
+                        w0 += fp_mulmod(kw[jj].x, mono[jj][0]);
+                        w1 += fp_mulmod(kw[jj].y, mono[jj][1]);
+                    }
+                }
+                const double p0 = fp_mulmod(x[2 * j], w0), p1 = fp_mulmod(x[2 * j + 1], w1);
+                // the chunk before lands now (its column: d - 1, or the last one of the pair before)
+                if (c > 0) {
+                    const int jb = (c - 1) / K1, db = (c - 1) % K1;
+                    if (db != 0) {
+                        __hip_atomic_fetch_add(&land[land_word[db] + W::handoff_word(t, 2 * jb)], late0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&land[land_word[db] + W::handoff_word(t, 2 * jb + 1)], late1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (d == 0) {
+                    own[2 * j] += p0;
+                    own[2 * j + 1] += p1;
+                } else {
+                    late0 = p0;
+                    late1 = p1;
+                }
+            }
+            {   // the last chunk (column K1 - 1 of the last pair: never the own one)
+                constexpr int jb = (CHUNKS - 1) / K1, db = (CHUNKS - 1) % K1;
+                __hip_atomic_fetch_add(&land[land_word[db] + W::handoff_word(t, 2 * jb)], late0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&land[land_word[db] + W::handoff_word(t, 2 * jb + 1)], late1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-
-        // ---- hand the other components theirs: clear, barrier, add, barrier -----------------------------------------------------------
-        W::sync();
-#pragma unroll
-        for (int m = 0; m < E; m++) mine[W::handoff_word(t, m)] = 0.0;
         __syncthreads();
-#pragma unroll
-        for (int d = 1; d < K1; d++)
-#pragma unroll
-            for (int m = 0; m < E; m++)
-                __hip_atomic_fetch_add(&land[d][W::handoff_word(t, m)], prod[d][m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __syncthreads();
+        if constexpr (FBS_GLWE_L2_AHEAD != 0) {
+            const uint32_t far_step = i + FBS_GLWE_L2_AHEAD < n_steps ? i + FBS_GLWE_L2_AHEAD : n_steps - 1;
+            const __amdgpu_buffer_rsrc_t far = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double *>(a.bsk_hat + (size_t)far_step * (GROUP == 2 ? 3 : 1) * rows * K1 * N), 0, row_lines * 128u, 0x00020000);
+            ahead_word = __builtin_amdgcn_raw_buffer_load_b32(far, ahead_off, 0, 0);
+        }
 
-        // ---- the total for this component ((k + 1) l products below 0.8 q each: centred by the transform first); accumulate ---------
-        double own[E];
+        // ---- the total for this component; its landing words cleared for their next turn; back to coefficients; accumulate -----------
 #pragma unroll
-        for (int m = 0; m < E; m++) own[m] = prod[0][m] + mine[W::handoff_word(t, m)];
-        W::sync();   // the inverse transform's stores stay behind these reads (same wave, same words)
-        W::template inverse<false>(own, xc, t, twi, W::inverse_uniform(t, twi));
+        for (int m = 0; m < E; m++) {
+            double *word = &land[land_word[0] + W::handoff_word(t, m)];
+            own[m] += *word;
+            *word = 0.0;
+        }
+        W::template inverse<false>(own, xc, t, twi, W::inverse_uniform(t, twi));   // (centred by the transform first)
 #pragma unroll
         for (int m = 0; m < E; m++) acc[m] = fp_center(acc[m] + own[m]);
     }
+
+    if constexpr (FBS_GLWE_L2_AHEAD != 0) asm volatile("" ::"v"(ahead_word));   // (never looked at; this keeps the loads)
 
     // ---- sample extraction of coefficient 0 (k mask polynomials, the body), plus the table's constant -----------------
     if (!live) return;
@@ -264,17 +332,32 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
     }
 }
 
-// bootstraps per workgroup: twelve waves where the registers allow three waves per SIMD (N <= 512), six to eight at N = 1024
+// Bootstraps per workgroup.  The THROUGHPUT shape fills a CU: twelve waves where the registers allow three waves per SIMD (N <= 512:
+// 4, 3, 2 bootstraps at k = 2, 3, 4), six to eight at N = 1024.  Launches that leave most of the chip empty take ONE bootstrap per
+// workgroup up to one per CU (every wave alone on its SIMD: a step is one wave's instruction chain, not three waves' sharing an issue
+// port) and two up to two per CU.  Measured at k = 3, N = 512, n = 614 (the 128-bit set for p <= 4), ms per launch: 64 / 256 bootstraps
+// 1.55 / 1.81 with one per workgroup against 3.32 / 3.37 with three; 512: 2.90 with two against 3.61; 768: 4.06 with three.
 template <int LOGN, int K1>
 constexpr int glwe_fpw() {
+#ifdef FBS_EXP_GLWE_FPW
+    return FBS_EXP_GLWE_FPW;
+#else
     return LOGN >= 10 ? 2 : 12 / K1;
+#endif
+}
+
+template <int LOGN, int K1, int GROUP, int FPW>
+static void launch_fpw(const BrArgs &a, hipStream_t stream, std::string *kernel) {
+    *kernel = "k_blind_rotate_glwe<" + std::to_string(LOGN) + "," + std::to_string(K1) + "," + std::to_string(GROUP) + "," + std::to_string(FPW) + ">";
+    hipLaunchKernelGGL((k_blind_rotate_glwe<LOGN, K1, GROUP, FPW>), dim3((unsigned)((a.count + FPW - 1) / FPW)), dim3(64 * K1 * FPW), 0, stream, a);
 }
 
 template <int LOGN, int K1, int GROUP>
-static void launch_one(const BrArgs &a, hipStream_t stream, std::string *kernel) {
-    constexpr int FPW = glwe_fpw<LOGN, K1>();
-    *kernel = "k_blind_rotate_glwe<" + std::to_string(LOGN) + "," + std::to_string(K1) + "," + std::to_string(GROUP) + ">";
-    hipLaunchKernelGGL((k_blind_rotate_glwe<LOGN, K1, GROUP, FPW>), dim3((unsigned)((a.count + FPW - 1) / FPW)), dim3(64 * K1 * FPW), 0, stream, a);
+static void launch_one(int fpw, const BrArgs &a, hipStream_t stream, std::string *kernel) {
+    constexpr int FULL = glwe_fpw<LOGN, K1>();
+    if (fpw == 1) launch_fpw<LOGN, K1, GROUP, 1>(a, stream, kernel);
+    else if (fpw == 2 && FULL > 2) launch_fpw<LOGN, K1, GROUP, (FULL > 2 ? 2 : FULL)>(a, stream, kernel);
+    else launch_fpw<LOGN, K1, GROUP, FULL>(a, stream, kernel);
 }
 
 // the shapes built: k = 2, 3, 4 at N = 256 and 512, k = 2, 3 at N = 1024; one or two key bits per step
@@ -288,14 +371,24 @@ bool glwe_shape_built(uint32_t log_n, uint32_t k) {
     return false;
 }
 
-bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream, std::string *kernel) {
+// bootstraps per workgroup of the throughput shape (what a full round is made of: glwe_full_fpw x CUs)
+int glwe_full_fpw(uint32_t log_n, uint32_t k) {
+#define X(L, K) \
+    if (log_n == L && k + 1 == K) return glwe_fpw<L, K>();
+    FBS_GLWE_SHAPES(X)
+#undef X
+    return 0;
+}
+
+// fpw: bootstraps per workgroup (1, 2, or anything else for the throughput shape)
+bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, int fpw, hipStream_t stream, std::string *kernel) {
     const fbs_params &p = ctx->p;
     if (p.k < 2 || !glwe_shape_built(p.log_n_poly, p.k)) return false;
-#define X(L, K)                                                      \
-    if (p.log_n_poly == L && p.k + 1 == K) {                         \
-        if (ctx->group == 2) launch_one<L, K, 2>(a, stream, kernel); \
-        else launch_one<L, K, 1>(a, stream, kernel);                 \
-        return true;                                                 \
+#define X(L, K)                                                           \
+    if (p.log_n_poly == L && p.k + 1 == K) {                              \
+        if (ctx->group == 2) launch_one<L, K, 2>(fpw, a, stream, kernel); \
+        else launch_one<L, K, 1>(fpw, a, stream, kernel);                 \
+        return true;                                                      \
     }
     FBS_GLWE_SHAPES(X)
 #undef X
@@ -303,11 +396,17 @@ bool launch_blind_rotate_glwe(fbs_ctx *ctx, const BrArgs &a, hipStream_t stream,
 }
 
 void blind_rotate_glwe_catalog(std::vector<std::string> *out) {
-#define X(L, K)                                                                                                   \
-    out->push_back("k_blind_rotate_glwe<" + std::to_string(L) + "," + std::to_string(K) + ",1>");                 \
-    out->push_back("k_blind_rotate_glwe<" + std::to_string(L) + "," + std::to_string(K) + ",2>");
+    std::vector<std::string> names;
+#define X(L, K)                                  \
+    for (int g = 1; g <= 2; g++)                 \
+        for (int fpw : {1, 2, glwe_fpw<L, K>()}) \
+            names.push_back("k_blind_rotate_glwe<" + std::to_string(L) + "," + std::to_string(K) + "," + std::to_string(g) + "," + std::to_string(fpw) + ">");
     FBS_GLWE_SHAPES(X)
 #undef X
+    // (a shape whose throughput form holds two bootstraps per workgroup lists "2" once)
+    std::sort(names.begin(), names.end());
+    names.erase(std::unique(names.begin(), names.end()), names.end());
+    out->insert(out->end(), names.begin(), names.end());
 }
 
 }  // namespace fbs

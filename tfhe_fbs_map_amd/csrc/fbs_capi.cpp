@@ -212,6 +212,7 @@ static int ctx_create(const fbs_params *params, uint64_t seed, const uint8_t *se
     ctx->tune.br_cu_max_per_cu = env_knob("FBS_BR_CU_MAX_PER_CU", ctx->tune.br_cu_max_per_cu);
     ctx->tune.br_cu_lean = env_knob("FBS_BR_CU_LEAN", ctx->tune.br_cu_lean);
     ctx->tune.br_k2_shape = env_knob("FBS_BR_K2_SHAPE", ctx->tune.br_k2_shape);
+    ctx->tune.br_glwe_fpw = env_knob("FBS_BR_GLWE_FPW", ctx->tune.br_glwe_fpw);
     rc = dev_supported(ctx.get());   // (is there a kernel instantiation for this shape?)
     if (rc != FBS_OK) return set_error(nullptr, rc, ctx->err);
 
@@ -258,7 +259,7 @@ int fbs_ctx_tune(fbs_ctx *ctx, const char *knob, int64_t value) try {
     int64_t *slot = k == "ks_gemm_min" ? &t.ks_gemm_min : k == "ks_mfma" ? &t.ks_mfma : k == "ks_fp" ? &t.ks_fp :
                     k == "ks_cols_major" ? &t.ks_cols_major : k == "ks_split" ? &t.ks_split : k == "br_whole_cu" ? &t.br_whole_cu :
                     k == "br_cu_kernel" ? &t.br_cu_kernel : k == "br_cu_max_per_cu" ? &t.br_cu_max_per_cu : k == "br_cu_lean" ? &t.br_cu_lean :
-                    k == "br_k2_shape" ? &t.br_k2_shape : nullptr;
+                    k == "br_k2_shape" ? &t.br_k2_shape : k == "br_glwe_fpw" ? &t.br_glwe_fpw : nullptr;
     if (!slot) return set_error(ctx, FBS_E_INVALID, "unknown knob '" + k + "'");
     if (value < 0) return set_error(ctx, FBS_E_INVALID, "knob values are non-negative");
     *slot = value;

@@ -45,6 +45,7 @@ struct Tune {
     int64_t br_cu_max_per_cu = 2;   // bootstraps per CU up to which a launch takes the one-bootstrap-per-CU kernel
     int64_t br_cu_lean = 1;         // 1: between one and two per CU, its 128-register variant (two workgroups per CU); 2: always; 0: never
     int64_t br_k2_shape = 0;        // k = 2: 0 by launch size; 3 always three waves per bootstrap; 12 always the twelve-wave latency shape
+    int64_t br_glwe_fpw = 0;        // k_blind_rotate_glwe: bootstraps per workgroup -- 0 by launch size; 1, 2; anything larger = the throughput shape
 };
 
 // ---- launch descriptors ------------------------------------------------------------------------

@@ -16,7 +16,7 @@ def instr(n, N, log_n, k, l, group):
     return steps * N * per_coef / 64.0
 
 
-def best_for(p, norm2, k, log_n, min_margin=6.0):
+def best_for(p, norm2, k, log_n, min_margin=6.0, groups=(1, 2)):
     q = float(MODULUS)
     N = 1 << log_n
     ns = np.arange(450, 1200, 2, dtype=np.float64)
@@ -28,7 +28,7 @@ def best_for(p, norm2, k, log_n, min_margin=6.0):
     for (l, beta) in _GADGETS:
         if (k + 1) * l > 20:
             continue
-        for group in (1, 2):
+        for group in groups:
             B = 2.0 ** beta
             key_term = (k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2
             round_term = (1 + k * N / 2.0) / (12.0 * B ** (2 * l))

@@ -3,7 +3,7 @@
 
     python3 tools/isa_count.py [pattern ...] > profiles/r03/isa_step_loop.txt
 
-Compiles csrc/fbs_blind_rotate.hip, fbs_blind_rotate_cu.hip and fbs_blind_rotate_k2.hip with the Makefile's flags to gfx950 assembly (`hipcc -S`), finds
+Compiles csrc/fbs_blind_rotate.hip, fbs_blind_rotate_cu.hip, fbs_blind_rotate_k2.hip and fbs_blind_rotate_glwe.hip with the Makefile's flags to gfx950 assembly (`hipcc -S`), finds
 every kernel whose demangled name matches one of the patterns (default: the instantiations the profile sets of
 tools/profile_round.sh time) and prints, for the basic blocks the compiler marks as inside a loop: vector (VALU) instructions, the
 FP64 share, the opcode histogram, and the kernel's register / scratch / LDS figures.  The PMC counter SQ_INSTS_VALU per wave and
@@ -58,7 +58,7 @@ def main():
     print("# python3 tools/isa_count.py: vector instructions in the loop blocks of each kernel, from hipcc -S (a nested loop's body is")
     print("# counted once: the headline kernel's level loop, 849 of the 2664, runs twice per step -> 3 513 per wave and step)")
     with tempfile.TemporaryDirectory() as tmp:
-        for src in ("fbs_blind_rotate.hip", "fbs_blind_rotate_cu.hip", "fbs_blind_rotate_k2.hip"):
+        for src in ("fbs_blind_rotate.hip", "fbs_blind_rotate_cu.hip", "fbs_blind_rotate_k2.hip", "fbs_blind_rotate_glwe.hip"):
             out = os.path.join(tmp, src + ".s")
             subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, os.path.join(CSRC, src)], check=True, stderr=subprocess.DEVNULL)
             found = list(kernels(open(out).read()))
