@@ -493,9 +493,9 @@ def secure_leg(B, local, steps, oracle_sample=32):
     the adder's linear combinations), 128-bit noise, 6 sigma: what a deployment would run.  The selector takes two key bits
     per blind-rotation step there (bsk_group = 2); the one-bit-per-step choice is timed beside it."""
     from tfhe_fbs_map_amd import Context, choose_params
-    from tfhe_fbs_map_amd.params import bootstrap_cost, margin_sigmas
+    from tfhe_fbs_map_amd.params import DEFAULT_GLWE_DIMS, bootstrap_cost, margin_sigmas
 
-    def one(prm):
+    def one(prm, B=B):
         ctx = Context(prm, seed=1, device=local)
         elapsed, prof, tables, cts, ids, _, out, ok = timed_batch(ctx, prm, B, 0, steps, 2, None)
         br, ks = prof["blind_rotate"], prof["keyswitch"]
@@ -522,6 +522,13 @@ def secure_leg(B, local, steps, oracle_sample=32):
     rec["n1024_p4"] = dict(one(small), note="128-bit set for p = 4 at norm2 = 2: the N = 1024 kernels at a secure parameter set")
     if choose_params(4, 2, glwe_dims=(1, 2)).k == 2:
         rec["n1024_p4"]["k2"] = one(choose_params(4, 2, glwe_dims=(1, 2)))
+    # ... and what ExecConfig() takes for p <= 8 at ordinary norms: GLWE dimension 3 at N = 512 (k N = 1536, between the two noise floors
+    # k = 1 offers) on k_blind_rotate_glwe, four waves per bootstrap, three bootstraps per workgroup -- a round of the chip is 3 x CUs
+    # bootstraps, so this leg is timed on two full rounds (a batch of 1 024 is cut into a round and a launch of its own for the rest)
+    k3 = choose_params(4, 2, glwe_dims=DEFAULT_GLWE_DIMS)
+    if k3.k == 3 and B >= 1024:
+        rec["n1024_p4"]["k3_n512"] = dict(one(k3, B=1536), note="the default 128-bit set for p = 4 (ExecConfig: glwe_dims = (1, 2, 3)): k = 3, N = 512, "
+                                                             "two key bits per step; two full rounds of 768 bootstraps")
     # BASELINE configs[4] (fbs_size = 31; no non-power-of-two N here: the 128-bit set is N = 2048 with two gadget levels)
     big = choose_params(31, 325)
     rec["p31"] = dict(one(big), note="128-bit set for p = 31 at norm2 = 325 (BASELINE configs[4]: fbs_size = 31)")

@@ -46,6 +46,8 @@ def test_headline_line_has_the_contract_fields():
     # every 128-bit leg holds a sample of its TIMED batch to the scalar oracle, word for word; at batch 256 the default
     # set runs on the twelve-wave latency shape; and the deployable number sits at the top level beside the benchmark shape
     legs = [s, s["k1"], s["one_key_bit_per_step"], s["n1024_p4"], s["n1024_p4"]["k2"], s["p31"], s["p31"]["one_key_bit_per_step"]]
+    if "k3_n512" in s["n1024_p4"]:                         # (timed on batches of a round or more only)
+        legs.append(s["n1024_p4"]["k3_n512"])
     assert all(leg["bit_exact_vs_oracle"] is True and "scalar oracle" in leg["oracle_sample"] for leg in legs)
     assert s["params"]["k"] == 2 and s["blind_rotate_kernel"] == "k_blind_rotate_cu_k2" and s["k1"]["params"]["k"] == 1
     v = d["value_secure"]

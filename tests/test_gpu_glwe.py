@@ -98,6 +98,85 @@ def test_launch_shapes_by_size_and_the_cut(nat, k, group):
     ctx.close()
 
 
+@pytest.mark.parametrize("p, norm2", [(4, 2), (7, 10)])
+def test_default_k3_sets_at_full_size_against_the_oracle(nat, p, norm2):
+    """What `LutExecEnv.eval` runs by default for p <= 8 at ordinary norms: the selector's own k = 3, N = 512 set at full n through
+    fbs_bootstrap_batch_dev -- two full rounds of the throughput shape (1 536 bootstraps: three per workgroup), word for word against the
+    oracle on ciphertexts that sit in every sub-slot of the first, a middle and the last workgroup, trivial ciphertexts beside
+    ordinary ones; 1 024, which the launcher CUTS into a round and a launch of one bootstrap per workgroup, checked at both ends and
+    either side of the cut; 500 (two per workgroup) and 200 (one)."""
+    import torch
+    from tfhe_fbs_map_amd.params import DEFAULT_GLWE_DIMS, choose_params, margin_sigmas, security_bits
+    prm = choose_params(p, norm2, glwe_dims=DEFAULT_GLWE_DIMS)
+    assert prm.k == 3 and prm.N == 512 and prm.bsk_group == 2 and prm.l_bsk == 1, "the selector moved: pin this test's parameter set"
+    assert security_bits(prm) >= 127.9 and margin_sigmas(prm, norm2) >= 6.0
+    ctx, o = nat.Context(prm, seed=1), orc.Oracle(prm, seed=1)
+    cus = ctx.stat("cu_count")
+    rng = np.random.default_rng(7 + p)
+    tables = [[0] + [int(v) for v in rng.integers(0, 2, p - 1)] for _ in range(16)]
+    tv = ctx.tvset(tables)
+    name = lambda fpw: "k_blind_rotate_glwe<9,4,2,%d>" % fpw
+    for B, pick, want in ((6 * cus, [0, 1, 2, 3, 4, 5, 3 * cus - 3, 3 * cus - 2, 3 * cus - 1, 3 * cus, 3 * cus + 1, 6 * cus - 3, 6 * cus - 2, 6 * cus - 1, 301, 1000], [name(3)]),
+                          (4 * cus, [0, 2, 3 * cus - 1, 3 * cus, 3 * cus + 1, 4 * cus - 2, 4 * cus - 1, 500, 900], [name(1), name(3)]),
+                          (500, [0, 1, 2, 3, 250, 498, 499], [name(2)]), (200, [0, 1, 100, 199], [name(1)])):
+        msgs = rng.integers(0, p, B)
+        ids = (np.arange(B) % 16).astype(np.uint32)
+        cts = ctx.encrypt(msgs, nonce0=100)
+        trivial = [pick[1], pick[-2]]
+        cts[trivial, :-1] = 0
+        d_in = torch.from_numpy(cts.view(np.int64)).cuda()
+        d_ids = torch.from_numpy(ids.view(np.int32)).cuda()
+        d_out = torch.empty_like(d_in)
+        ctx.profile(True)
+        ctx.profile_read(reset=True)
+        ctx.bootstrap_batch_dev(tv, d_in.data_ptr(), d_ids.data_ptr(), B, d_out.data_ptr())
+        ctx.sync()
+        assert sorted(k for k in ctx.profile_kernels() if "blind_rotate" in k) == sorted(want), (B, ctx.profile_kernels())
+        got = d_out.cpu().numpy().view(np.uint64)
+        ref, _ = o.bootstrap_batch(cts[pick], tables, ids[pick])
+        assert np.array_equal(got[pick], ref), B
+        keep = np.ones(B, bool)
+        keep[trivial] = False
+        assert np.array_equal(ctx.decrypt(got)[keep], np.array([tables[i][m] for i, m in zip(ids, msgs)])[keep])
+    ctx.close()
+
+
+def test_noise_model_holds_at_k3(nat):
+    """The variance model the selector rests on, at the k = 3 set for (7, 10): the measured bootstrap OUTPUT noise (the blind
+    rotation's term: k + 1 = 4 key polynomials' noise per step of two key bits, rounding seen through a key of k N = 1536 bits)
+    against params.variances, every output far inside its box; and -- the modulus switch onto 2N = 1024 slots is the term that
+    sets n at this size -- a linear combination of squared norm 10 of bootstrap outputs, bootstrapped again, decrypts."""
+    from tfhe_fbs_map_amd.params import DEFAULT_GLWE_DIMS, choose_params, variances
+    prm = choose_params(7, 10, glwe_dims=DEFAULT_GLWE_DIMS)
+    assert prm.k == 3 and prm.N == 512
+    ctx, o = nat.Context(prm, seed=13), orc.Oracle(prm, seed=13)
+    rng = np.random.default_rng(5)
+    table = [0] + [int(v) for v in rng.integers(0, 2, 6)]
+    B = 600
+    msgs = rng.integers(0, 7, B)
+    cts = ctx.encrypt(msgs, nonce0=900)
+    out = ctx.bootstrap_batch(ctx.tvset([table]), cts)
+    assert np.array_equal(ctx.decrypt(out), [table[m] for m in msgs])
+    phase = o.phase(out).astype(object)
+    want = np.array([table[m] for m in msgs], dtype=object) * (2 * o.delta_half)
+    err = np.array([min((int(p) - int(w)) % orc.Q, (int(w) - int(p)) % orc.Q) for p, w in zip(phase, want)], dtype=np.float64)
+    predicted = np.sqrt(variances(prm)[0]) * orc.Q
+    measured = float(np.sqrt(np.mean(err ** 2)))
+    assert 0.5 * predicted < measured < 1.25 * predicted, (measured, predicted)
+    assert err.max() < 0.1 * orc.Q / (4 * 7)
+    # 3 x b0 + b1 (squared norm 10) of bootstrap outputs, bootstrapped again
+    bits = np.array([table[m] for m in msgs])
+    idx = rng.integers(0, B, (2, B))
+    coefs = np.array([3, 1])
+    value = (coefs[:, None] * bits[idx]).sum(0)                      # 0 .. 4 < 7
+    lc = np.zeros_like(out)
+    for c, row in zip(coefs, idx):
+        lc = (lc + int(c) * out[row].astype(object)) % orc.Q
+    again = ctx.bootstrap_batch(ctx.tvset([list(range(7))]), lc.astype(np.uint64))
+    assert np.array_equal(ctx.decrypt(again), value)
+    ctx.close()
+
+
 def run_program(nat, prm, name, T, fuse=False):
     from tfhe_fbs_map_amd import parse_fbs
     rec = load_fixture(name)

@@ -119,8 +119,10 @@ class ExecConfig:
     # 2.0-2.4 ms per launch of up to one bootstrap per CU where the k = 1 sets' whole-CU kernels take 2.6-2.9.  So the choice no
     # longer depends on how wide a program's levels are (rounds 3's `wide_level`), nor on how many ranks it is cut over: every
     # rank of a sharded run derives the same set from (p, norm2) -- shared rotations (fuse_tables) included: the accumulator rows
-    # and the extraction kernel are general in k since round 4.
-    glwe_dims: tuple = (1, 2)
+    # and the extraction kernel are general in k since round 4.  k = 3 (N = 512, two key bits per step: k_blind_rotate_glwe, k + 1
+    # waves per bootstrap) sits between the two noise floors k N = 1024 and 2048 and is what p <= 8 takes at ordinary norms: 183-208 k
+    # FBS/s in full rounds where the k = 2 sets give 151-164 k, 1.5-1.9 ms per launch of up to one bootstrap per CU where they take 2.0-2.4.
+    glwe_dims: tuple = (1, 2, 3)          # (= params.DEFAULT_GLWE_DIMS)
     max_programs: int = 8                 # loaded programs kept per ExecConfig (least recently used evicted)
     _contexts: dict = field(default_factory=dict, repr=False)
     _programs: "OrderedDict" = field(default_factory=OrderedDict, repr=False)

@@ -141,12 +141,43 @@ def bootstrap_cost(prm: Params) -> float:
     pairs = 1.0 if prm.bsk_group != 2 else (0.74 if l == 1 else 0.79 if (l == 2 and prm.log_n_poly == 11) else 1.25)
     # GLWE dimension k = 2 at N = 1024 (k_blind_rotate_pairs_k2, round 3: three wave-private 1024-point transforms each way on three
     # waves per bootstrap, twelve waves per CU), MEASURED: 7.50 ms per 1024 bootstraps at n = 760 against P1024's 9.26
-    if k == 2:
+    if k == 2 and prm.log_n_poly == 10 and prm.bsk_group == 2 and l == 1:
         pairs = 0.867
+    elif k >= 2:
+        # every other k >= 2 (k_blind_rotate_glwe: k + 1 waves per bootstrap): modelled instructions times what the kernel was MEASURED
+        # to take per modelled instruction, shape by shape (profiles/r04/glwe_calibration.txt), over P1024's 9.2 ms per 1 024
+        # (a further level costs a step more than its instructions -- its transform hangs on the one before: at p = 2, 566 steps of
+        # two levels at k = 2 take 1.93 ms per launch of 64 where 570 steps of one level at k = 3 take 1.44, at the same throughput)
+        return (glwe_instructions(prm) / 1e6 * glwe_ms_per_minstr(prm.log_n_poly, k) / 9.2 * (1.0 + 0.04 * (l - 1))
+                + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0))
     return 0.988 * pairs * blind(n, l, N, prm.log_n_poly) / blind(630, 3, 1024, 10, 1) + 0.012 * (k * N * t * (n + 1)) / (1024 * 8 * 631.0)
 
 
+def glwe_shape_built(k: int, log_n: int) -> bool:
+    """Is there a blind-rotation kernel for GLWE dimension k >= 2 at N = 2^log_n (csrc/fbs_blind_rotate_glwe.hip: FBS_GLWE_SHAPES)?"""
+    return (k in (2, 3, 4) and log_n in (8, 9)) or (k in (2, 3) and log_n == 10)
+
+
+def glwe_instructions(prm: Params) -> float:
+    """FP64 wave-instructions per bootstrap of k_blind_rotate_glwe, modelled: per step and coefficient (k+1) [(l+1) transforms of log N / 2
+    butterflies of 8 + (k+1) l products of 7 -- four times that with two key bits per step, the bundle's three products included -- + 2 l
+    for the digits + 12 for rounding and re-centring], n (or n / 2) steps, 64 lanes."""
+    k, l, group = prm.k, prm.l_bsk, prm.bsk_group if prm.bsk_group == 2 else 1
+    per_coef = (k + 1) * ((l + 1) * 4.0 * prm.log_n_poly + 7.0 * (k + 1) * l * (4 if group == 2 else 1) + 2.0 * l + 12.0)
+    return prm.n / group * prm.N * per_coef / 64.0
+
+
+# ms per 1 024 bootstraps per million modelled instructions, in full rounds of workgroups (tools/glwe_calibrate.py on the 128-bit sets
+# for p = 4 of every shape; k_blind_rotate_pairs_k2<10,4> on the same scale: 2.48): by (log2 N, k), the slower of one / two key bits per step
+GLWE_MS_PER_MINSTR = {(8, 4): 3.04, (9, 2): 2.47, (9, 3): 2.70, (9, 4): 3.04, (10, 2): 3.37, (10, 3): 2.69}
+
+
+def glwe_ms_per_minstr(log_n: int, k: int) -> float:
+    return GLWE_MS_PER_MINSTR.get((log_n, k), 3.1)
+
+
 # ---- selector ------------------------------------------------------------------------------------------------------
+DEFAULT_GLWE_DIMS = (1, 2, 3)    # the GLWE dimensions ExecConfig admits (fbs_exec_env.ExecConfig.glwe_dims)
 REFERENCE_MARGIN = 4.0          # the optimizer's default p_error is "4 sigma" (concrete.patch:56: default_value_t = _4_SIGMA)
 
 _GADGETS = [(l, beta) for l in (1, 2, 3, 4, 5, 6) for beta in range(3, 24) if 10 <= l * beta <= 30]
@@ -170,11 +201,12 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     switch over 1..23 levels of 1..6 bits.  security = None with `sigma`: the same search at a fixed noise (the
     reduced-noise benchmark setting).  `groups`: key bits per blind-rotation step to consider (2 = the multi-bit form: half
     the steps on bundles of three GGSW samples, 1.5x the key, more noise per step; built for N >= 1024, l <= 5, even n).
-    `glwe_dims`: GLWE dimensions to consider.  k = 2 is built at N = 1024 with two key bits per step and one gadget level
-    (k_blind_rotate_pairs_k2): the noise floor of k N = 2048 on 1024-point transforms, 0.81 of k = 1 at N = 2048 per bootstrap in
-    launches of a round (1 024) or more and ahead from ~400 per launch -- but up to one bootstrap per CU it takes 3.4-3.6 ms
-    where the k = 1 sets' whole-CU kernels take 2.8, so it is for WIDE levels: callers that know their launch sizes ask for it
-    (ExecConfig does, by the program's bootstraps per level times the samples).
+    `glwe_dims`: GLWE dimensions to consider.  k = 2 at N = 1024 with two key bits per step and one gadget level has kernels of its
+    own (k_blind_rotate_pairs_k2, k_blind_rotate_cu_k2): the noise floor of k N = 2048 on 1024-point transforms, what p = 15 takes at
+    ordinary norms.  Every other k = 2, 3, 4 at N = 256 / 512 (k <= 3 at N = 1024), any depth, one or two key bits per step, runs on
+    k_blind_rotate_glwe (k + 1 waves per bootstrap) and is priced by that kernel's measured cost: k = 3 at N = 512 -- k N = 1536, a
+    noise floor between the two k = 1 offers, on 512-point transforms -- is what p <= 7 takes (183-208 k FBS/s in full rounds against
+    151-164 k at k = 2, 1.6-1.9 ms per launch of up to one bootstrap per CU against 2.0-2.4).
     Cost = `bootstrap_cost`.  Raises ValueError when nothing reaches `min_margin`
     (p too large for N <= 4096 at this security level); with `floor_margin` the requirement is first relaxed in steps of
     half a sigma down to that floor."""
@@ -197,17 +229,17 @@ def choose_params(p: int, norm2: float = 1.0, min_margin: float = 6.0, security:
     need = (1.0 / (4.0 * p) / min_margin) ** 2              # largest admissible variance
     best = None
     for k, log_n in [(k_, ln) for k_ in glwe_dims for ln in poly_sizes]:
-        if k == 2 and (log_n != 10 or 2 not in groups):
-            continue                                        # what the k = 2 kernel is built for
+        if k >= 2 and not glwe_shape_built(k, log_n):
+            continue                                        # no kernel for this (k, N)
         N = 1 << log_n
         s_glwe = (sigma_min(k * N, security) if security is not None else (sigma if sigma is not None else REDUCED_SIGMA)) / q
         v_ms = (1 + ns / 4.0) / (12.0 * (2.0 * N) ** 2)
         if (v_ms >= need).all():
             continue
         for (l, beta), group in [((l_, b_), g_) for (l_, b_) in _GADGETS for g_ in groups]:
-            if group == 2 and (log_n < 10 or l > 5):
+            if group == 2 and k == 1 and (log_n < 10 or l > 5):
                 continue
-            if k == 2 and (group != 2 or l != 1):
+            if (k + 1) * l > 20:
                 continue
             B = 2.0 ** beta
             key_term = (k + 1) * l * N * (B * B + 2) / 12.0 * s_glwe ** 2

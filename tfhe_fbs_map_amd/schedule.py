@@ -69,6 +69,7 @@ def split_range(total, parts, r):
 #               its lean variant / small workgroups / k_blind_rotate<10,6,3,4>
 #   "k2"        k = 2, N = 1024, two key bits per step, n = 734 (the default 128-bit sets for p <= 15 at small norms):
 #               k_blind_rotate_cu_k2 for one, two, three rounds of one bootstrap per CU, k_blind_rotate_pairs_k2<10,4> beyond
+#   "k3"        k = 3, N = 512, two key bits per step, n = 614 (the default 128-bit sets for p <= 8): k_blind_rotate_glwe<9,4,2,1 / 2 / 3>
 #   "n2048"     k = 1, N = 2048, two key bits per step, one level, n = 714 (p = 15 at heavy norms; shared rotations):
 #               k_blind_rotate_cu_pairs<11,1> up to one per CU, k_blind_rotate_pairs<11,7,4> beyond
 #   "n2048_l2"  the same with two levels, n = 766 (p = 31, BASELINE configs[4]): k_blind_rotate_cu_pairs<11,2>, round after round
@@ -78,6 +79,10 @@ LAUNCH_FAMILIES = {
     "p1024": dict(steps=630, stairs=LAUNCH_MS_P1024, round_ms=ROUND_MS_P1024, full_from=896),
     "k2": dict(steps=367, stairs=((1, 2.08), (128, 2.21), (256, 2.46), (257, 4.54), (512, 4.55), (513, 6.6), (768, 6.5), (769, 6.87), (896, 7.04),
                                   (1024, 7.39)), round_ms=7.3, full_from=769),
+    # k = 3 at N = 512, two key bits per step, one level, n = 614 (the default 128-bit sets for p <= 8 at ordinary norms): k_blind_rotate_glwe with
+    # one bootstrap per workgroup up to one per CU, two up to two, three beyond -- a ROUND is 768 bootstraps; longer launches are cut
+    "k3": dict(steps=307, stairs=((1, 1.52), (128, 1.60), (256, 1.81), (257, 2.60), (512, 2.90), (513, 3.60), (768, 4.06)), round_ms=3.75, full_from=513,
+               round=768),
     "n2048": dict(steps=357, stairs=((1, 2.52), (128, 2.59), (256, 2.86), (257, 4.69), (512, 4.86), (513, 7.8), (768, 7.4), (769, 9.66), (1024, 9.34)),
                   round_ms=9.0, full_from=769),
     "n2048_l2": dict(steps=383, stairs=((1, 4.10), (128, 4.06), (256, 4.41), (257, 9.0), (512, 8.23), (513, 13.6), (768, 12.2), (769, 18.2), (1024, 16.34)),
@@ -92,6 +97,8 @@ def launch_family(params):
     steps = params.n // 2 if params.bsk_group == 2 else params.n
     if params.k == 2 and params.N == 1024 and params.bsk_group == 2 and params.l_bsk == 1:
         name = "k2"
+    elif params.k == 3 and params.N == 512 and params.bsk_group == 2 and params.l_bsk == 1:
+        name = "k3"
     elif params.N == 2048 and params.bsk_group == 2 and params.l_bsk <= 2:
         name = "n2048" if params.l_bsk == 1 else "n2048_l2"
     elif params.N == 1024 and params.bsk_group != 2 and params.l_bsk == 3:
@@ -109,7 +116,7 @@ def launch_ms(count, cost=1.0, params=None):
         return 0.0
     name, scale = launch_family(params) if params is not None else ("p1024", cost)
     fam = LAUNCH_FAMILIES[name]
-    rounds, rest = divmod(int(count), 1024)
+    rounds, rest = divmod(int(count), fam.get("round", 1024))     # (a round: the bootstraps the throughput shape holds on the whole chip)
     if rounds and rest >= fam["full_from"]:
         rounds, rest = rounds + 1, 0
     ms = rounds * fam["round_ms"] + (0.1 if rounds == 1 and not rest else 0.0)   # (the first round of a launch: fill and drain)

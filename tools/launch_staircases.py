@@ -9,8 +9,9 @@ from tfhe_fbs_map_amd import Context, P1024, choose_params
 from tfhe_fbs_map_amd.schedule import launch_family, launch_ms
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-SIZES = (1, 64, 128, 256, 257, 384, 512, 513, 640, 768, 769, 896, 1024, 1124, 1280, 1536, 2048)
+SIZES = (1, 64, 128, 256, 257, 384, 512, 513, 640, 768, 769, 896, 1024, 1124, 1280, 1536, 2048, 2304, 3072)
 SETS = (("p1024", P1024), ("k2", choose_params(15, 70, glwe_dims=(1, 2))), ("k2 (p = 4)", choose_params(4, 2, glwe_dims=(1, 2))),
+        ("k3", choose_params(4, 2, glwe_dims=(1, 2, 3))), ("k3 (p = 7)", choose_params(7, 10, glwe_dims=(1, 2, 3))),
         ("n2048", choose_params(15, 70)), ("n2048_l2", choose_params(31, 325)))
 print("# python3 tools/launch_staircases.py %d  on %s" % (steps, torch.cuda.get_device_name(0)))
 print("# per launch of B bootstraps: ms measured (key switch + blind rotation, HIP events in the library) | modelled by schedule.launch_ms | kernels")

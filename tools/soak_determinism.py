@@ -1,6 +1,6 @@
 """Race hunt for the whole-CU kernels: every launch shape that shares LDS words between phases (hand-over = inverse exchange =
 re-deal in k_blind_rotate_cu_pairs; accumulator words = hand-over in k_blind_rotate_cu; exchange buffer = landing words of the LDS
-atomics in the k = 2 kernels) is run REPS times on the same inputs at
+atomics in the k = 2 kernels; landing words of the general-GLWE kernel taken in turns) is run REPS times on the same inputs at
 full n, with every CU busy, and every run must give the first run's ciphertexts bit for bit; the first run is checked against the
 expected cleartexts.  A race shows as a rare mismatch.   python3 tools/soak_determinism.py [reps = 40]"""
 import os, sys
@@ -17,7 +17,12 @@ CASES = [("P1024", P1024, (64, 256, 300, 512)), ("p15 128-bit", choose_params(15
          # atomics and read the total back, between two barriers per step (csrc/fbs_blind_rotate_k2.hip) -- one, two and four
          # bootstraps per workgroup
          ("p15 128-bit k=2", choose_params(15, 70, glwe_dims=(1, 2)), (200, 256, 300, 512, 1024, 1124)),
-         ("p4 128-bit k=2", choose_params(4, 2, glwe_dims=(1, 2)), (256, 1024))]
+         ("p4 128-bit k=2", choose_params(4, 2, glwe_dims=(1, 2)), (256, 1024)),
+         # GLWE dimension 3 at N = 512 (k_blind_rotate_glwe, csrc/fbs_blind_rotate_glwe.hip): products ADDED into the other components'
+         # landing words as they are made, two sets of landing words taken in turns, ONE barrier per step -- one, two and three
+         # bootstraps per workgroup, a launch the launcher cuts
+         ("p4 128-bit k=3", choose_params(4, 2, glwe_dims=(1, 2, 3)), (200, 256, 500, 768, 1024, 1536)),
+         ("p7 128-bit k=3", choose_params(7, 10, glwe_dims=(1, 2, 3)), (256, 768))]
 bad = 0
 for label, prm, sizes in CASES:
     ctx = Context(prm, seed=5)
