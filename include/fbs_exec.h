@@ -55,7 +55,7 @@ extern "C" {
 typedef struct fbs_params {
     uint32_t n;          /* small LWE dimension (P1024: 630)                      */
     uint32_t log_n_poly; /* log2 of the GLWE polynomial size N (P1024: 10)        */
-    uint32_t k;          /* GLWE dimension: 1, or 2 at N = 1024 with bsk_group = 2, l_bsk = 1 */
+    uint32_t k;          /* GLWE dimension: 1 (N = 256 .. 4096); 2, 3, 4 at N = 256 / 512; 2, 3 at N = 1024 (any l_bsk, bsk_group 1 or 2) */
     uint32_t l_bsk;      /* blind-rotation gadget levels (3)                      */
     uint32_t beta_bsk;   /* log2 blind-rotation gadget base (7)                   */
     uint32_t t_ksk;      /* key-switch levels (8)                                 */

@@ -81,7 +81,7 @@ LAUNCH_FAMILIES = {
                                   (1024, 7.39)), round_ms=7.3, full_from=769),
     # k = 3 at N = 512, two key bits per step, one level, n = 614 (the default 128-bit sets for p <= 8 at ordinary norms): k_blind_rotate_glwe with
     # one bootstrap per workgroup up to one per CU, two up to two, three beyond -- a ROUND is 768 bootstraps; longer launches are cut
-    "k3": dict(steps=307, stairs=((1, 1.52), (128, 1.60), (256, 1.81), (257, 2.60), (512, 2.90), (513, 3.60), (768, 4.06)), round_ms=3.75, full_from=513,
+    "k3": dict(steps=307, stairs=((1, 1.62), (64, 1.55), (128, 1.60), (256, 1.80), (257, 2.52), (512, 2.85), (513, 3.62), (768, 4.00)), round_ms=3.72, full_from=513,
                round=768),
     "n2048": dict(steps=357, stairs=((1, 2.52), (128, 2.59), (256, 2.86), (257, 4.69), (512, 4.86), (513, 7.8), (768, 7.4), (769, 9.66), (1024, 9.34)),
                   round_ms=9.0, full_from=769),

@@ -23,6 +23,9 @@ rec p63 822 1 1024
 rec p4 638 1 1024
 rec securek2 734 2 1024
 rec p4k2 630 2 1024
+rec p4k3 614 2 1536
+rec p7k3 682 2 1536
+rec k3cu256 614 2 256
 rec k2cu256 734 2 256
 rec k2cu512 734 2 512
 rec secure256 714 2 256

@@ -7,6 +7,7 @@
 #         p31g1 (the same with one key bit per step), p63 (N = 4096, one key bit per step), p4 (N = 1024 128-bit set),
 #         securek2 / p4k2 (GLWE dimension k = 2 at N = 1024: k_blind_rotate_pairs_k2 at the 128-bit sets for p = 15 and p = 4),
 #         secure256 / p31cu (the p = 15 and p = 31 sets at one bootstrap per CU), lean512 (bench.py --batch 512: two workgroups per CU),
+#         p4k3 / p7k3 (GLWE dimension 3 at N = 512: k_blind_rotate_glwe at the default 128-bit sets for p = 4 and p = 7, two full rounds of 768), k3cu256 (one bootstrap per workgroup),
 #         k2cu256 / k2cu512 (the k = 2 set for p = 15 on k_blind_rotate_cu_k2: one bootstrap on the twelve waves of a workgroup, one / two rounds)
 TAG=${1:-r04}; shift
 SETS=${@:-p1024 cu256 secure p31}
@@ -40,6 +41,9 @@ for S in $SETS; do
     p4)      run_set p4 python3 tools/secure_bench.py 1024 5 4 2 ;;
     securek2) run_set securek2 python3 tools/secure_bench.py 1024 5 15 70 k2 ;;
     p4k2)    run_set p4k2 python3 tools/secure_bench.py 1024 5 4 2 k2 ;;
+    p4k3)    run_set p4k3 python3 tools/secure_bench.py 1536 5 4 2 k3 ;;
+    p7k3)    run_set p7k3 python3 tools/secure_bench.py 1536 5 7 10 k3 ;;
+    k3cu256) run_set k3cu256 python3 tools/secure_bench.py 256 8 4 2 k3 ;;
     secure256) run_set secure256 python3 tools/secure_bench.py 256 8 15 70 ;;
     k2cu256) run_set k2cu256 python3 tools/secure_bench.py 256 8 15 70 k2 ;;
     k2cu512) run_set k2cu512 python3 tools/secure_bench.py 512 6 15 70 k2 ;;

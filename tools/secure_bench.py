@@ -1,5 +1,5 @@
 """A 128-bit-secure parameter set (params.choose_params(p, norm2); default p = 15, norm2 = 70: what the `secure` leg of bench.py
-times) on a flat batch, alone, for rocprofv3 --pmc passes:  secure_bench.py [batch] [steps] [p] [norm2] [key bits per step | k2]"""
+times) on a flat batch, alone, for rocprofv3 --pmc passes:  secure_bench.py [batch] [steps] [p] [norm2] [key bits per step | k2 | k3]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,8 +10,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 p_msg = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 norm2 = float(sys.argv[4]) if len(sys.argv) > 4 else 70
-if len(sys.argv) > 5 and sys.argv[5] == "k2":       # GLWE dimension 2 admitted (N = 1024, two key bits per step: wide launches)
+if len(sys.argv) > 5 and sys.argv[5] == "k2":       # GLWE dimension 2 admitted (N = 1024, two key bits per step)
     prm = choose_params(p_msg, norm2, glwe_dims=(1, 2))
+elif len(sys.argv) > 5 and sys.argv[5] == "k3":     # ... and 3 (N = 512): what ExecConfig() admits
+    prm = choose_params(p_msg, norm2, glwe_dims=(1, 2, 3))
 else:
     prm = choose_params(p_msg, norm2, groups=(int(sys.argv[5]),)) if len(sys.argv) > 5 else choose_params(p_msg, norm2)
 ctx = Context(prm, seed=1)

@@ -42,7 +42,7 @@ for name in fixture_names():
 sets = {}
 summary = dict(samples=T, fixtures=len(rows), all_ok=not bad, failures=bad, bootstraps=sum(r["nb_bootstrap"] for r in rows) * T,
                rotations=sum((r["rotations"] or 0) for r in rows) * T, programs_with_shared_rotations=sum(r["shared_rotations"] for r in rows),
-               poly_sizes=sorted({r["N"] for r in rows if r["N"]}), programs_at_glwe_dimension_2=sum(1 for r in rows if r.get("k") == 2),
+               poly_sizes=sorted({r["N"] for r in rows if r["N"]}), programs_at_glwe_dimension_2=sum(1 for r in rows if r.get("k") == 2), programs_at_glwe_dimension_3=sum(1 for r in rows if r.get("k") == 3),
                seconds=round(time.time() - t_all, 1), rows=rows)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(summary, open("gpurun_out/%s_all_fixtures.json" % ("reduced_noise" if os.environ.get("REDUCED_NOISE") else "secure"), "w"), indent=1)
