@@ -28,7 +28,10 @@
 // Issue priority by turns among the three waves of a SIMD (s_setprio 2 / 1 / 0 or 2 / 0 / 0, rotated every step or every half
 // step -- what gives the benchmark kernel's TWO waves per SIMD 10 %): 7.28-7.36 against 7.30 ms per 1 024, nothing either way
 // (profiles/r04/k2_turns_ab.txt); and with every step reading the same two key rows (-DFBS_EXP_HOT_KEYS) 7.18 against 7.18: no
-// key word is waited for from beyond L2 (profiles/r04/hot_keys_l2_ahead.txt).)
+// key word is waited for from beyond L2 (profiles/r04/hot_keys_l2_ahead.txt).  And the products as a software pipeline over chunks
+// (register pair, column) -- the key words of chunk c + 1 asked for before chunk c is multiplied, its products landing behind the next
+// chunk's, the first chunk ahead of the clearing barrier: what took k_blind_rotate_glwe from 8.9 to 7.3 ms, where the compiler had left
+// one load in flight -- 7.23-7.28 against 7.24-7.25 ms per 1 024 here: a pair's nine loads at the top of its iteration are flight enough.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
