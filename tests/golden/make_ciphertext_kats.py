@@ -47,6 +47,11 @@ SETS = {
     # bootstraps per CU it prefers the twelve-waves-per-bootstrap shape); LAYOUTS below says which of its 773 ciphertexts are ordinary.  The n = 760 entry above stays: it is the freeze that predates the kernel.
     "secure_p15_k2_shipped_n734_four_per_workgroup": dict(n=734, log_n_poly=10, k=2, l_bsk=1, beta_bsk=21, t_ksk=7, gamma_ksk=2, p_msg=15,
                                                           sigma_lwe=737229119, sigma_glwe=4, bsk_group=2),
+    # (end of round 4) GLWE dimension k = 3 at N = 512, two key bits per step (k_blind_rotate_glwe): the set the selector ships for
+    # (4, 2) once glwe_dims = (1, 2, 3) is the default -- in a batch of 2 x 256 CUs + 6, long enough for the launcher to take the
+    # throughput shape (three bootstraps per workgroup); LAYOUTS says which ciphertexts are ordinary
+    "secure_p4_k3_n512_shipped_three_per_workgroup": dict(n=614, log_n_poly=9, k=3, l_bsk=1, beta_bsk=18, t_ksk=11, gamma_ksk=1, p_msg=4,
+                                                          sigma_lwe=6737066039, sigma_glwe=280, bsk_group=2),
     "secure_p4_n1024": dict(n=638, log_n_poly=10, k=1, l_bsk=2, beta_bsk=8, t_ksk=12, gamma_ksk=1, p_msg=4, sigma_lwe=4328098537,
                             sigma_glwe=3511592, bsk_group=1),
 }
@@ -57,7 +62,9 @@ COUNT = 5
 # name -> (batch size, positions of the ORDINARY ciphertexts): every other ciphertext of the batch is trivial (mask zero, so every
 # blind-rotation step is skipped: milliseconds in the oracle, and on the GPU a bootstrap that only keeps its workgroup's barriers
 # company).  The ordinary ones sit in all four sub-slots of the first workgroup, in a middle one, and in the ragged last one.
-LAYOUTS = {"secure_p15_k2_shipped_n734_four_per_workgroup": (773, [0, 1, 2, 3, 386, 769, 771, 772])}
+LAYOUTS = {"secure_p15_k2_shipped_n734_four_per_workgroup": (773, [0, 1, 2, 3, 386, 769, 771, 772]),
+           # (three bootstraps per workgroup: every sub-slot of the first one, a middle one, the ragged last one of 518 = 172 x 3 + 2)
+           "secure_p4_k3_n512_shipped_three_per_workgroup": (518, [0, 1, 2, 259, 515, 516, 517])}
 
 
 def digest(a):

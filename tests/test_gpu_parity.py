@@ -488,6 +488,8 @@ def test_ciphertext_kats_on_the_gpu(nat):
             out = ctx.bootstrap_batch(ctx.tvset(kat["tables"]), cts, np.array(kat["table_ids"], np.uint32))
             if "four_per_workgroup" in name:                         # the KAT cut for the throughput shape of the k = 2 kernel
                 assert "k_blind_rotate_pairs_k2<10,4>" in ctx.profile_kernels(), ctx.profile_kernels()
+            if "three_per_workgroup" in name:                        # ... and of the general-GLWE kernel at k = 3, N = 512
+                assert "k_blind_rotate_glwe<9,4,2,3>" in ctx.profile_kernels(), ctx.profile_kernels()
             ctx.profile(False)
             assert digest(out) == kat["sha256"]["outputs"], name
             assert [int(v) for v in ctx.decrypt(out)] == kat["decrypts_to"], name

@@ -35,9 +35,6 @@
 #ifndef FBS_GLWE_L2_AHEAD
 #define FBS_GLWE_L2_AHEAD 2
 #endif
-#ifndef FBS_GLWE_DEAL
-#define FBS_GLWE_DEAL 1
-#endif
 
 namespace fbs {
 
@@ -69,12 +66,10 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
     // twiddle tables; psi^x, x < N (two key bits per step)
     __shared__ __attribute__((aligned(16))) double lds_all[(1 + SETS) * WAVES * N + 2 * N + (GROUP == 2 ? N : 0)];
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // bootstrap of the workgroup, GLWE component.  The waves of a workgroup are dealt round the four SIMDs, and the waves that hold
-    // the SAME component of different bootstraps ask for the same key words: they must sit on DIFFERENT SIMDs to run side by side and
-    // find each other's lines in L1 -- with four components wave w and w + 4 would share a SIMD, so bootstrap s takes its components
-    // rotated by s (measured at k = 3, N = 512, n = 570: FBS_GLWE_DEAL below)
-    const uint32_t sub = wave / (uint32_t)K1, in_sub = wave - (uint32_t)K1 * sub;
-    const uint32_t comp = (K1 % 4 == 0 && FBS_GLWE_DEAL) ? (in_sub + sub) % (uint32_t)K1 : in_sub;
+    // bootstrap of the workgroup, GLWE component.  (Measured and dropped: with four components the waves that hold the SAME component of
+    // different bootstraps -- which ask for the same key words -- are four apart and would share a SIMD if the waves of a workgroup are
+    // dealt round the SIMDs in order; bootstrap s taking its components rotated by s changed nothing: 5.55 / 11.10 against 5.55 / 11.11 ms.)
+    const uint32_t sub = wave / (uint32_t)K1, comp = wave - (uint32_t)K1 * sub;
     const uint32_t t = threadIdx.x & 63u;
     double *mine = lds_all + wave * N;
     double *landing = lds_all + WAVES * N;
@@ -356,7 +351,7 @@ template <int LOGN, int K1, int GROUP>
 static void launch_one(int fpw, const BrArgs &a, hipStream_t stream, std::string *kernel) {
     constexpr int FULL = glwe_fpw<LOGN, K1>();
     if (fpw == 1) launch_fpw<LOGN, K1, GROUP, 1>(a, stream, kernel);
-    else if (fpw == 2 && FULL > 2) launch_fpw<LOGN, K1, GROUP, (FULL > 2 ? 2 : FULL)>(a, stream, kernel);
+    else if (fpw == 2) launch_fpw<LOGN, K1, GROUP, (FULL < 2 ? FULL : 2)>(a, stream, kernel);
     else launch_fpw<LOGN, K1, GROUP, FULL>(a, stream, kernel);
 }
 
