@@ -133,3 +133,12 @@ def test_layouts_are_priced_on_the_staircase_of_the_set_actually_loaded():
     assert 5.0 < a["predicted_speedup"] <= 8.0
     gate = [c for c in choose_sharding([300, 400], 4, 8, params=k2)["candidates"] if c["gate_groups"] == 8][0]
     assert gate["allgather_ms"] > 0
+    # the k = 3, N = 512 family (the default sets for p <= 8): a round of the chip is 768 bootstraps, one bootstrap per workgroup up to one
+    # per CU, two up to two; a launch of a round + 256 is cut and costs the two launches; ahead of the k = 2 set at every size
+    k3, k2p4 = choose_params(4, 2, glwe_dims=(1, 2, 3)), choose_params(4, 2, glwe_dims=(1, 2))
+    assert launch_family(k3) == ("k3", 1.0) and launch_family(choose_params(7, 10, glwe_dims=(1, 2, 3)))[0] == "k3"
+    assert launch_ms(256, params=k3) < 1.9 < 2.4 < launch_ms(257, params=k3) < launch_ms(512, params=k3) < 3.0 < launch_ms(768, params=k3) < 4.2
+    assert abs(launch_ms(1024, params=k3) - (launch_ms(768, params=k3) + launch_ms(256, params=k3))) < 0.2
+    assert launch_ms(3072, params=k3) < 4.05 * launch_ms(768, params=k3)
+    for B in (1, 64, 256, 512, 768, 1024, 1536, 3072, 6144):
+        assert launch_ms(B, params=k3) < launch_ms(B, params=k2p4), B

@@ -129,6 +129,32 @@ def test_exec_estimate_is_the_references_total_cost_in_this_executors_unit():
     assert costs == sorted(costs)
 
 
+def test_glwe_dimension_three_at_n512_for_small_plaintext_moduli():
+    """k N = 1536 is a noise floor between the two k = 1 offers: with k = 3 admitted (ExecConfig's default since the end of round 4) p <= 8
+    at ordinary norms takes N = 512 with two key bits per step and one level (k_blind_rotate_glwe), at the margin and the security
+    asked, cheaper by the kernel's MEASURED cost; p = 15 and heavy norms keep what they had; shapes without a kernel are never returned."""
+    from tfhe_fbs_map_amd import ExecConfig
+    from tfhe_fbs_map_amd.params import (DEFAULT_GLWE_DIMS, bootstrap_cost, choose_params, glwe_instructions, glwe_shape_built, margin_sigmas,
+                                        security_bits)
+    assert DEFAULT_GLWE_DIMS == (1, 2, 3) == ExecConfig(seed=1).glwe_dims
+    for p, norm2 in ((2, 1), (3, 2), (4, 2), (4, 8), (7, 10), (8, 10)):
+        a, b = choose_params(p, norm2, glwe_dims=(1, 2)), choose_params(p, norm2, glwe_dims=DEFAULT_GLWE_DIMS)
+        assert (b.k, b.N, b.l_bsk, b.bsk_group) == (3, 512, 1, 2), (p, norm2, b)
+        assert margin_sigmas(b, norm2) >= 6.0 and security_bits(b) >= 127.9 and bootstrap_cost(b) < (0.93 if a.N == 1024 else 1.0) * bootstrap_cost(a)
+    assert choose_params(15, 70, glwe_dims=DEFAULT_GLWE_DIMS) == choose_params(15, 70, glwe_dims=(1, 2))
+    assert choose_params(7, 59, glwe_dims=DEFAULT_GLWE_DIMS).k == 2 and choose_params(15, 281, glwe_dims=DEFAULT_GLWE_DIMS).k == 1
+    assert choose_params(31, 325, glwe_dims=DEFAULT_GLWE_DIMS) == choose_params(31, 325)
+    for k in (2, 3, 4, 5):
+        for log_n in (8, 9, 10, 11):
+            assert glwe_shape_built(k, log_n) == ((k <= 4 and log_n <= 9) or (k <= 3 and log_n == 10))
+    for dims in ((1, 2, 3, 4, 5), (4, 5)):
+        for p, norm2 in ((2, 1), (4, 2)):
+            s = choose_params(p, norm2, glwe_dims=dims, poly_sizes=(8, 9, 10, 11, 12))
+            assert s.k == 1 or glwe_shape_built(s.k, s.log_n_poly)
+    prm = choose_params(4, 2, glwe_dims=DEFAULT_GLWE_DIMS)
+    assert abs(glwe_instructions(prm) - 307 * 512 * 4 * (2 * 4.0 * 9 + 7.0 * 4 * 4 + 2 + 12) / 64.0) < 1e-6
+
+
 def test_glwe_dimension_two_is_an_option_not_the_default():
     """k = 2 (N = 1024, two key bits per step, one level: what k_blind_rotate_pairs_k2 is built for) is returned only when asked
     for, where it is cheaper and reaches the margin; ExecConfig asks for it for every program (since the twelve-wave latency
