@@ -32,6 +32,10 @@
 #ifndef FBS_GLWE_CHUNKS_AHEAD
 #define FBS_GLWE_CHUNKS_AHEAD 1
 #endif
+// -DFBS_EXP_GLWE_FLAT_PSI=1 (experiments only: WRONG results): the psi^x look-ups at conflict-free addresses
+#ifndef FBS_EXP_GLWE_FLAT_PSI
+#define FBS_EXP_GLWE_FLAT_PSI 0
+#endif
 #ifndef FBS_GLWE_L2_AHEAD
 #define FBS_GLWE_L2_AHEAD 2
 #endif
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
 #pragma unroll
                         for (int jj = 0; jj < 3; jj++) {
                             const uint32_t xx = (e[jj] * (o_lane + c0)) & (2u * N - 1u);
-                            const double v = psi[xx & (N - 1)];
+                            const double v = psi[FBS_EXP_GLWE_FLAT_PSI ? ((t + (uint32_t)jj) & (N - 1)) : (xx & (N - 1))];
                             const int hi = __double2hiint(v) ^ (int)((xx << (31 - LOGN)) & 0x80000000u);
                             mono[jj][0] = __hiloint2double(hi, __double2loint(v)) - 1.0;
                             if (twins) {
