@@ -50,6 +50,11 @@ def test_ragged_batches_bit_exact(nat, log_n, k, l, beta, group):
         if B > 2:
             cts[B - 1, :-1] = 0
             cts[B // 2, :] = orc.Q - 1
+            # every other step skipped (both rotation amounts of the pair zero): the landing sets take turns by the steps EXECUTED
+            n = prm.n
+            skip = np.arange(n).reshape(-1, 2)[1::2].reshape(-1) if group == 2 else np.arange(1, n, 2)
+            cts[0, skip] = 0
+            cts[1, skip[: len(skip) // 2]] = 0
         ctx.profile(True)
         ctx.profile_read(reset=True)
         got = ctx.bootstrap_batch(tv, cts, ids)

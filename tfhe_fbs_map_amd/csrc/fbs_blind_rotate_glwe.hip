@@ -149,6 +149,7 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
     const uint32_t ahead_off = threadIdx.x < slice_lines && ahead_line < row_lines ? ahead_line * 128u : 0x7FFFFFF0u;
     uint32_t ahead_word = 0;
     uint32_t e0_next = ms[0], e1_next = GROUP == 2 ? ms[1] : 0u;
+    uint32_t turn = 0;   // steps this bootstrap has executed (wave-uniform, the same in every wave of the bootstrap)
     for (uint32_t i = 0; i < n_steps; i++) {
         uint32_t e[3];
         e[0] = __builtin_amdgcn_readfirstlane(e0_next);
@@ -156,7 +157,6 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
         // (ms has n + 1 entries: the last step reads the body word, or re-reads it, and ignores it)
         e0_next = ms[STEP_BITS * (i + 1) < a.n ? STEP_BITS * (i + 1) : a.n];
         if constexpr (GROUP == 2) e1_next = ms[2 * i + 3 < a.n ? 2 * i + 3 : a.n];
-        double *land = landing + (SETS == 2 ? (i & 1u) * (uint32_t)(WAVES * N) : 0u);   // this step's set of landing words
         if (e[0] == 0 && e[1] == 0) {   // nothing to add for this bootstrap: the others of the workgroup still meet their barriers
             if constexpr (FPW > 1) {
                 if constexpr (SETS == 1) __syncthreads();
@@ -164,6 +164,11 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
             }
             continue;
         }
+        // this step's set of landing words.  The sets take turns by the steps this BOOTSTRAP executes (not by i: a skipped step has no
+        // barrier when the bootstrap is alone in its workgroup), so between two uses of a set there is always an executed step, whose
+        // barrier every wave of the bootstrap passes after the owner has read and cleared the set
+        double *land = landing + (SETS == 2 ? (turn & 1u) * (uint32_t)(WAVES * N) : 0u);
+        turn++;
         e[2] = (e[0] + e[1]) & (2u * N - 1u);
 
         // ---- what is decomposed: (X^r - 1) ACC_c (one key bit per step) or ACC_c itself, rounded to the closest multiple of q / B^l ----
