@@ -19,7 +19,8 @@ def main():
     name, T, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
     k2 = len(sys.argv) > 4 and sys.argv[4] in ("k2", "fused_k2")   # GLWE dimension 2 at N = 1024: ciphertexts and rows of 2 N + 1 words
-    fused = fused or (len(sys.argv) > 4 and sys.argv[4] == "fused_k2")   # ... with shared rotations: rows of 3 N words
+    fused = fused or (len(sys.argv) > 4 and sys.argv[4] in ("fused_k2", "fused_k3"))   # ... with shared rotations: rows of (k + 1) N words
+    k3 = len(sys.argv) > 4 and sys.argv[4] in ("k3", "fused_k3")   # GLWE dimension 3 at N = 512 (k_blind_rotate_glwe): 3 N + 1 words, rows of 4 N
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -33,6 +34,8 @@ def main():
     if k2:
         from tests.helpers import toy_k2
         prm = toy_k2(p)
+    if k3:
+        prm = Params(n=12, log_n_poly=9, k=3, l_bsk=1, beta_bsk=18, t_ksk=8, gamma_ksk=2, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=4, bsk_group=2)
     ctx = Context(prm, seed=21)                       # keys replicated: every rank derives them from the seed
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
                    low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fused)

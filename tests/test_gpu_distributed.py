@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("name,T,flavour", [("adder8__search_p7", 5, ""), ("adder8__basic_p2", 3, ""), ("edge_outputs", 4, ""),
                                             ("full_adder__search_p7", 1, ""),   # T = 1: levels narrower than the world, empty slices
-                                            ("adder8__search_p7", 5, "k2"), ("edge_outputs", 4, "k2")])   # GLWE dimension 2
+                                            ("adder8__search_p7", 5, "k2"), ("edge_outputs", 4, "k2"),    # GLWE dimension 2
+                                            ("adder8__search_p7", 5, "k3"), ("edge_outputs", 4, "k3")])   # ... and 3 at N = 512 (the default for p <= 8)
 def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T, flavour):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     out = str(tmp_path / "res.npz")
@@ -44,7 +45,7 @@ def test_two_ranks_on_one_gpu_bit_identical(tmp_path, name, T, flavour):
     assert total // 2 - int(z["depth"]) <= int(z["gate_fbs"]) <= -(-total // 2) + int(z["depth"])      # rank 0 did half
 
 
-@pytest.mark.parametrize("flavour", ["fused", "fused_k2"])
+@pytest.mark.parametrize("flavour", ["fused", "fused_k2", "fused_k3"])
 def test_two_ranks_on_a_fused_program(tmp_path, flavour):
     """A program loaded with FBS_LOAD_FUSE_TABLES (several tables on one blind rotation), cut across two ranks both ways.  Gate-
     sharded, the unit dealt out is the ROTATION: rows are (k + 1) N words, a shared rotation's accumulator travels in its row, and
