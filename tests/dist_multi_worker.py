@@ -27,6 +27,8 @@ def main():
     low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
     p = max(7, max(len(t) for t in low["tables"]))
     prm = toy_k2(p) if flavour == "k2" else Params(n=12, log_n_poly=10, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=1 << 8)
+    if flavour == "k3":                               # GLWE dimension 3 at N = 512: the default shape for p <= 8 (k_blind_rotate_glwe)
+        prm = Params(n=12, log_n_poly=9, k=3, l_bsk=1, beta_bsk=18, t_ksk=8, gamma_ksk=2, p_msg=p, sigma_lwe=1 << 8, sigma_glwe=4, bsk_group=2)
     ctx = Context(prm, seed=21, device=local)         # keys replicated: every rank derives them from the seed
     prog = Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
                    low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=flavour == "fused")

@@ -44,7 +44,7 @@ def launch(world, script_args, timeout=900):
 
 @needs_two
 @pytest.mark.parametrize("name,T,flavour", [("adder8__search_p7", 5, ""), ("edge_outputs", 4, ""), ("full_adder__search_p7", 1, ""),
-                                            ("adder8__basic_p2", 4, "fused"), ("adder8__search_p7", 5, "k2")])
+                                            ("adder8__basic_p2", 4, "fused"), ("adder8__search_p7", 5, "k2"), ("adder8__search_p7", 5, "k3")])
 def test_sharded_runners_on_rccl_bit_identical(tmp_path, name, T, flavour):
     for world in world_sizes():
         out = str(tmp_path / ("res%d.npz" % world))
@@ -89,7 +89,7 @@ def test_bench_two_gpus_reports_rccl_legs():
     assert d["sharded"]["params"]["security_bits_estimate"] >= 127.9
 
 
-@pytest.mark.parametrize("flavour", ["", "fused", "k2"])
+@pytest.mark.parametrize("flavour", ["", "fused", "k2", "k3"])
 def test_the_worker_itself_on_one_rank(tmp_path, flavour):
     """The worker of the tests above with world size 1 on the nccl backend -- on ANY GPU box, the one-GPU ones included: the file
     that waits for a multi-GPU node is at least run end to end (process group, layouts, the npz it hands back) where this build

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction counts of the blind-rotation kernels' step loops, from the compiler's assembly (no GPU needed).
 
-    python3 tools/isa_count.py [pattern ...] > profiles/r03/isa_step_loop.txt
+    python3 tools/isa_count.py [pattern ...] > profiles/r04/isa_step_loop.txt
 
 Compiles csrc/fbs_blind_rotate.hip, fbs_blind_rotate_cu.hip, fbs_blind_rotate_k2.hip and fbs_blind_rotate_glwe.hip with the Makefile's flags to gfx950 assembly (`hipcc -S`), finds
 every kernel whose demangled name matches one of the patterns (default: the instantiations the profile sets of
@@ -21,7 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 DEFAULT = [r"k_blind_rotate<10, 6, 3, 4, true>", r"k_blind_rotate<10, 6, 3, 1, true>", r"k_blind_rotate<10, 6, 6, 1, true>",
            r"k_blind_rotate<11, 7, 4, 1, true>", r"k_blind_rotate<11, 7, 5, 1, true>", r"k_blind_rotate<12, 8, 5, 1, true>",
            r"k_blind_rotate_pairs<11, 7, 4>", r"k_blind_rotate_cu<10, 3, 2, false>", r"k_blind_rotate_cu<10, 3, 2, true>",
-           r"k_blind_rotate_cu_pairs<11, 1>", r"k_blind_rotate_cu_pairs<11, 2>", r"k_blind_rotate_pairs_k2<10, 4>"]
+           r"k_blind_rotate_cu_pairs<11, 1>", r"k_blind_rotate_cu_pairs<11, 2>", r"k_blind_rotate_pairs_k2<10, 4>", r"k_blind_rotate_cu_k2",
+           r"k_blind_rotate_glwe<9, 4, 2, 3>", r"k_blind_rotate_glwe<9, 4, 2, 1>"]
 
 
 def demangle(names):
