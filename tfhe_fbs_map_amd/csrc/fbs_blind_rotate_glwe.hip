@@ -32,6 +32,11 @@
 #ifndef FBS_GLWE_CHUNKS_AHEAD
 #define FBS_GLWE_CHUNKS_AHEAD 1
 #endif
+// ... with one bootstrap per workgroup (every wave alone on its SIMD, 512 registers to itself): k = 3, N = 512, n = 614, ms per launch of
+// 64 / 256: 1: 1.56 / 1.78, 2: 1.50 / 1.70, 3: 1.50 / 1.73, 5: 1.53 / 1.77
+#ifndef FBS_GLWE_CHUNKS_AHEAD_ALONE
+#define FBS_GLWE_CHUNKS_AHEAD_ALONE 2
+#endif
 // -DFBS_EXP_GLWE_FLAT_PSI=1 (experiments only: WRONG results): the psi^x look-ups at conflict-free addresses
 #ifndef FBS_EXP_GLWE_FLAT_PSI
 #define FBS_EXP_GLWE_FLAT_PSI 0
@@ -216,7 +221,8 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
             // 48 loads of a step; k = 3 at N = 512, n = 614: 8.9 ms per 1 536 bootstraps against 7.3 now).  Here the words of chunk c + AHEAD are asked for
             // BEFORE chunk c is multiplied, and the products of chunk c land while chunk c + 1 is multiplied: a chunk's words have AHEAD
             // chunks of arithmetic to arrive in.  The first chunks of a level are asked for ahead of its transform.
-            constexpr int CHUNKS = (E / 2) * K1, AHEAD = FBS_GLWE_CHUNKS_AHEAD < CHUNKS ? FBS_GLWE_CHUNKS_AHEAD : CHUNKS - 1, BUFS = AHEAD + 1;
+            constexpr int CHUNKS = (E / 2) * K1, WANT = FPW == 1 ? FBS_GLWE_CHUNKS_AHEAD_ALONE : FBS_GLWE_CHUNKS_AHEAD;
+            constexpr int AHEAD = WANT < CHUNKS ? WANT : CHUNKS - 1, BUFS = AHEAD + 1;
             double2 kbuf[BUFS][NS];
             auto request = [&](int c, double2 (&k)[NS]) {
                 const int j = c / K1, d = c % K1;
