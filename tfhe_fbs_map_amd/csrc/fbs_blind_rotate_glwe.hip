@@ -346,11 +346,14 @@ __global__ __launch_bounds__(64 * K1 * FPW) void k_blind_rotate_glwe(BrArgs a) {
 // 4, 3, 2 bootstraps at k = 2, 3, 4), six to eight at N = 1024.  Launches that leave most of the chip empty take ONE bootstrap per
 // workgroup up to one per CU (every wave alone on its SIMD: a step is one wave's instruction chain, not three waves' sharing an issue
 // port) and two up to two per CU.  Measured at k = 3, N = 512, n = 614 (the 128-bit set for p <= 4), ms per launch: 64 / 256 bootstraps
-// 1.55 / 1.81 with one per workgroup against 3.32 / 3.37 with three; 512: 2.90 with two against 3.61; 768: 4.06 with three.
+// 1.55 / 1.81 with one per workgroup against 3.32 / 3.37 with three; 512: 2.90 with two against 3.61; 768: 4.06 with three.  (FOUR per workgroup
+// there -- sixteen waves at 128 registers with 196 bytes spilled, one set of landing words -- 6.99 against 5.43 ms per 1 024, 20.6 against 14.5 per 3 072.)
 template <int LOGN, int K1>
 constexpr int glwe_fpw() {
-#ifdef FBS_EXP_GLWE_FPW
+#ifdef FBS_EXP_GLWE_FPW       // (experiments: every shape)
     return FBS_EXP_GLWE_FPW;
+#elif defined(FBS_EXP_GLWE_FPW_K3N512)   // (experiments: k = 3 at N = 512 only)
+    return LOGN == 9 && K1 == 4 ? FBS_EXP_GLWE_FPW_K3N512 : LOGN >= 10 ? 2 : 12 / K1;
 #else
     return LOGN >= 10 ? 2 : 12 / K1;
 #endif
