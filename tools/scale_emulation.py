@@ -34,6 +34,7 @@ from tfhe_fbs_map_amd.distributed import GpuBackend, allgather_ms, choose_shardi
 CONFIGS = {"adder128__search_p15": "BASELINE configs[0]/[1] stand-in (EPFL adder.blif is fetched from the network by the reference)",
            "mul16__search_p15": "BASELINE configs[2] stand-in (ISCAS85 c6288 = 16x16 multiplier)",
            "trivium_stream_v2__search_p15": "BASELINE configs[3] stand-in (EPFL log2.blif is not available offline)",
+           "basic_adder128": "a 128-bit ripple-carry adder lowered gate by gate (p = 3): a small plaintext modulus on the default k = 3 sets (--secure k3)",
            "adder128__search_p31": "BASELINE configs[4] (fbs_size = 31): the 128-bit adder mapped @31; run with --secure (p = 31 at N = 2048, l = 2)"}
 
 
@@ -52,15 +53,26 @@ class Timer:
 
 
 def measure(name, T, ranks_list, all_ranks, secure):
-    rec = load_fixture(name)
-    env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
-    low = env.lower()
-    p = int(name.rsplit("_p", 1)[-1])
+    if name.startswith("basic_adder"):
+        # a ripple-carry adder built gate by gate and lowered like the reference's MapToFBSBasic (one linear combination + one table per
+        # two-input gate: p = 3) -- no fixture of that size exists; what a small plaintext modulus looks like on several ranks
+        from tfhe_fbs_map_amd.fbs_exec_env import min_fbs_size
+        from tfhe_fbs_map_amd.netlist import map_basic
+        from tools.fusion_bench import ripple_adder
+        env = map_basic(ripple_adder(int(name[len("basic_adder"):])))
+        low = env.lower()
+        p = min_fbs_size(low["tables"])
+    else:
+        rec = load_fixture(name)
+        env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"])
+        low = env.lower()
+        p = int(name.rsplit("_p", 1)[-1])
     if secure:
         from tfhe_fbs_map_amd import choose_params
-        # (--secure k2: GLWE dimension 2 admitted, as ExecConfig does for every program since the twelve-wave latency shape made
-        # it the faster choice at every launch size: one GPU and every rank run the SAME set; --secure k1: the k = 1 sets only)
-        prm = choose_params(p, env.stats()["norm2_linprod"], glwe_dims=(1, 2) if secure == "k2" else (1,))
+        from tfhe_fbs_map_amd.params import DEFAULT_GLWE_DIMS
+        # (--secure k2: GLWE dimension 2 admitted; --secure k3: 2 and 3, what ExecConfig admits for every program -- each ahead of the
+        # alternatives at every launch size, so one GPU and every rank run the SAME set; --secure k1: the k = 1 sets only)
+        prm = choose_params(p, env.stats()["norm2_linprod"], glwe_dims={"k2": (1, 2), "k3": DEFAULT_GLWE_DIMS}.get(secure, (1,)))
     else:
         prm = params_for(p)
     ctx = Context(prm, seed=1)
@@ -163,7 +175,7 @@ def main():
     ap.add_argument("--samples", default="1000,64")
     ap.add_argument("--ranks", default="2,4,8")
     ap.add_argument("--all-ranks", action="store_true")
-    ap.add_argument("--secure", nargs="?", const="k1", default=None, choices=["k1", "k2"],
+    ap.add_argument("--secure", nargs="?", const="k1", default=None, choices=["k1", "k2", "k3"],
                     help="the 128-bit set chosen for each program instead of the reduced-noise benchmark set (k2: GLWE dimension 2 admitted)")
     ap.add_argument("--skip", default="trivium_stream_v2__search_p15:1000", help="circuit:samples pairs to leave out (minutes of GPU each)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "scale_emulation.json"))
