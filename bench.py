@@ -404,6 +404,10 @@ def run_batch(args, rank, world, local, dist):
                "; k=1 N=%d: %.0f" % (sec["k1"]["params"]["N"], sec["k1"]["value"]) if "k1" in sec else "",
                p4["value"], p4["params"]["n"], p4["params"]["k"], p4["params"]["l"], sec["p31"]["value"], sec["p31"]["params"]["n"],
                sec["p31"]["params"]["N"], sec["p31"]["params"]["l"], sec["p31"]["params"]["key_bits_per_step"]))
+        k3 = sec["n1024_p4"].get("k3_n512")
+        if k3:                                                               # the default set for p <= 8: GLWE dimension 3 at N = 512
+            result["config"]["secure_summary"] += "; p=4 at the default set (n=%d N=%d k=%d, two full rounds of %d) %.0f FBS/s" % (
+                k3["params"]["n"], k3["params"]["N"], k3["params"]["k"], k3["batch"] // 2, k3["value"])
     return result
 
 
