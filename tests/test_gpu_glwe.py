@@ -225,6 +225,40 @@ def test_shared_rotations(nat, k, log_n, group):
     assert prog.n_rotations < prog.n_bootstrap
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+def test_levels_longer_than_a_round_are_cut_the_same_ciphertexts(nat, fuse):
+    """A program whose levels are longer than a round of the throughput shape (3 x CUs bootstraps at k = 3) with a small rest: the
+    launcher cuts every such level -- whole rounds, then the rest as a launch of its own, with shared rotations into the rest's own
+    accumulator rows -- and every output ciphertext equals what two evaluations of half the samples each (no level reaches a round)
+    give; the cut really happened (both launch shapes in the profile)."""
+    from tfhe_fbs_map_amd import parse_fbs
+    rec = load_fixture("adder8__basic_p2")
+    prm = toy(l_bsk=1, beta_bsk=18, bsk_group=2, p_msg=7)
+    ctx = nat.Context(prm, seed=6)
+    low = parse_fbs(rec["fbs"], inputs=rec["program_inputs"]).lower()
+    prog = nat.Program(ctx, ctx.tvset(low["tables"]), len(low["input_names"]), low["kind"], low["arg0"], low["arg1"],
+                       low["const_coef"], low["term_coef"], low["term_src"], low["out_wire"], fuse_tables=fuse)
+    cus = ctx.stat("cu_count")
+    widest = max(prog.level_width)
+    T = (3 * cus + 2 * cus - 8) // widest                      # the widest level: a round and a rest of up to two bootstraps per CU
+    assert widest * T > 3 * cus and widest * T - 3 * cus <= 2 * cus and widest * (T // 2) <= 3 * cus
+    ins, expect = subsample(rec, 8)
+    reps = -(-T // 8)
+    cts = ctx.encrypt(np.stack([np.tile(ins[n], reps)[:T] for n in low["input_names"]]), nonce0=9)
+    ctx.profile(True)
+    ctx.profile_read(reset=True)
+    whole = prog.eval(cts, T)
+    kernels = [k for k in ctx.profile_kernels() if "blind_rotate" in k]
+    assert "k_blind_rotate_glwe<9,4,2,3>" in kernels and any(k.endswith(",1>") or k.endswith(",2>") for k in kernels), kernels
+    h = T // 2
+    halves = np.concatenate([prog.eval(np.ascontiguousarray(cts[:, :h]), h), prog.eval(np.ascontiguousarray(cts[:, h:]), T - h)], axis=1)
+    assert np.array_equal(whole, halves)
+    for j, name in enumerate(low["out_names"]):
+        if low["out_wire"][j] >= 0:
+            assert np.array_equal(ctx.decrypt(whole[j])[:8], expect[name]), name
+    ctx.close()
+
+
 def test_unbuilt_shapes_are_refused_with_a_code(nat):
     """k = 4 at N = 1024, k = 5, k >= 2 at N = 2048: no kernel -- an error code and a message at context creation, not a launch."""
     from tfhe_fbs_map_amd import FbsError, Params
