@@ -259,6 +259,24 @@ def test_levels_longer_than_a_round_are_cut_the_same_ciphertexts(nat, fuse):
     ctx.close()
 
 
+@pytest.mark.parametrize("k, log_n, l, group", [(3, 9, 1, 2), (2, 9, 2, 1)])
+def test_imported_keys_at_other_glwe_dimensions(nat, k, log_n, l, group):
+    """fbs_import_keys on such a set: the oracle's keys under another seed (rows (component, level), k mask columns and the body; three
+    samples per pair of key bits with two key bits per step: include/fbs_exec.h) are accepted and bootstrap exactly as the oracle does; a
+    key with the body and a mask column exchanged is refused by the decryption check."""
+    from tfhe_fbs_map_amd import FbsError
+    prm = toy(log_n_poly=log_n, k=k, l_bsk=l, beta_bsk=18 // l, bsk_group=group)
+    o, ctx = orc.Oracle(prm, seed=78), nat.Context(prm, seed=5, keygen=False)
+    keys = o.keys()
+    swapped = keys["bsk"].reshape(-1, k + 1, prm.N)[:, ::-1].copy().reshape(-1)
+    with pytest.raises(FbsError, match="does not decrypt"):
+        ctx.import_keys(keys["sk_lwe"], keys["sk_glwe"], swapped, keys["ksk"])
+    ctx.import_keys(**keys)
+    cts = o.encrypt(np.arange(7), nonce0=4)
+    assert np.array_equal(ctx.bootstrap_batch(ctx.tvset([TABLES[0]]), cts), o.bootstrap_batch(cts, [TABLES[0]], None)[0])
+    ctx.close()
+
+
 def test_unbuilt_shapes_are_refused_with_a_code(nat):
     """k = 4 at N = 1024, k = 5, k >= 2 at N = 2048: no kernel -- an error code and a message at context creation, not a launch."""
     from tfhe_fbs_map_amd import FbsError, Params
