@@ -31,7 +31,9 @@
 // key word is waited for from beyond L2 (profiles/r04/hot_keys_l2_ahead.txt).  And the products as a software pipeline over chunks
 // (register pair, column) -- the key words of chunk c + 1 asked for before chunk c is multiplied, its products landing behind the next
 // chunk's, the first chunk ahead of the clearing barrier: what took k_blind_rotate_glwe from 8.9 to 7.3 ms, where the compiler had left
-// one load in flight -- 7.23-7.28 against 7.24-7.25 ms per 1 024 here: a pair's nine loads at the top of its iteration are flight enough.)
+// one load in flight -- 7.23-7.28 against 7.24-7.25 ms per 1 024 here: a pair's nine loads at the top of its iteration are flight enough.
+// And the 48 ds_add_f64 of a step as plain stores (wrong results, a timing experiment: what any hand-over without atomics could
+// save at most): 7.27 against 7.18 ms -- the landings are not what the step waits for either.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
