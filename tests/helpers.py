@@ -47,6 +47,19 @@ def toy_k2(p_msg=7, n=12, beta=21):
                   bsk_group=2)
 
 
+def toy_k3(p_msg=7, n=12, beta=18):
+    """A toy set of the k = 3 shape the default 128-bit sets for p <= 8 run on (GLWE dimension 3 at N = 512, one gadget level, two key
+    bits per step: k_blind_rotate_glwe, ciphertexts of 3 N + 1 = 1537 words, accumulator rows of 4 N)."""
+    from tfhe_fbs_map_amd import Params
+    return Params(n=n, log_n_poly=9, k=3, l_bsk=1, beta_bsk=beta, t_ksk=8, gamma_ksk=2, p_msg=p_msg, sigma_lwe=1 << 8, sigma_glwe=4,
+                  bsk_group=2)
+
+
+def toy_glwe(k, p_msg=7, n=12):
+    """toy_k2 / toy_k3 by GLWE dimension"""
+    return toy_k2(p_msg, n) if k == 2 else toy_k3(p_msg, n)
+
+
 def subsample(rec, T):
     """First T samples of the harness inputs and of the expected outputs."""
     ins = {k: v[:T] for k, v in rec["inputs"].items()}

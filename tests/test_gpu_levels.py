@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import lut_oracle, tfhe_oracle as orc
-from tests.helpers import load_fixture, oracle_eval_program, subsample, toy_k2
+from tests.helpers import load_fixture, oracle_eval_program, subsample, toy_glwe
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def load(nat, toy_params, name, T, seed=6, merge=True, k=1):
     ops, outs = lut_oracle.read_fbs(rec["fbs"])
     tables = [op[3] for op in ops if op[0] == "boot"]
     p = max(7, max(len(t) for t in tables))
-    prm = toy_params.replace(p_msg=p) if k == 1 else toy_k2(p)
+    prm = toy_params.replace(p_msg=p) if k == 1 else toy_glwe(k, p)
     ctx = nat.Context(prm, seed=seed)
     env = parse_fbs(rec["fbs"], inputs=rec["program_inputs"], merge_linear_prods=merge)
     low = env.lower()
@@ -78,7 +78,8 @@ def test_wire_slots_are_reused(nat, toy_params, name):
 
 
 @pytest.mark.parametrize("name,T,k", [("adder8__basic_p2", 5, 1), ("adder8__search_p7", 4, 1), ("edge_outputs", 3, 1), ("aes_sbox__basic_p2", 2, 1),
-                                      ("adder8__search_p7", 4, 2), ("adder8__basic_p2", 5, 2), ("edge_outputs", 3, 2)])
+                                      ("adder8__search_p7", 4, 2), ("adder8__basic_p2", 5, 2), ("edge_outputs", 3, 2),
+                                      ("adder8__search_p7", 4, 3), ("adder8__basic_p2", 5, 3)])
 def test_levels_in_slices_through_rows_and_back(nat, toy_params, name, T, k):
     """Every level cut into three ragged slices (cuts inside a gate's samples and between gates that share a source),
     each slice bootstrapped into a contiguous row buffer and scattered back -- the gate-sharded data path on one GPU
@@ -149,7 +150,7 @@ def one_rank_nccl():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,T,k", [("adder8__search_p7", 5, 1), ("adder8__basic_p2", 4, 1), ("edge_outputs", 3, 1), ("adder8__search_p7", 5, 2)])
+@pytest.mark.parametrize("name,T,k", [("adder8__search_p7", 5, 1), ("adder8__basic_p2", 4, 1), ("edge_outputs", 3, 1), ("adder8__search_p7", 5, 2), ("adder8__search_p7", 5, 3)])
 def test_runners_on_rccl_equal_program_eval(nat, toy_params, one_rank_nccl, name, T, k):
     """GateShardedRunner (send rows -> all_gather_into_tensor -> scatter, forced even with one rank) and
     SampleShardedRunner on the nccl backend == fbs_eval, word for word (k = 2: rows of 2 N + 1 words)."""

@@ -60,12 +60,12 @@ def random_program(seed):
     return env, boots
 
 
-@pytest.mark.parametrize("seed,k", [(s, 1) for s in range(12)] + [(s, 2) for s in (0, 3, 5, 8)])
+@pytest.mark.parametrize("seed,k", [(s, 1) for s in range(12)] + [(s, 2) for s in (0, 3, 5, 8)] + [(s, 3) for s in (1, 4, 7, 9)])
 def test_random_program(seed, k):
-    """k = 2: the same programs on a context of GLWE dimension 2 (ciphertexts of 2 N + 1 words through the linear combinations,
-    the level calls and k_blind_rotate_pairs_k2)."""
+    """k = 2, 3: the same programs on a context of GLWE dimension 2 at N = 1024 / 3 at N = 512 (ciphertexts of k N + 1 words through the
+    linear combinations, the level calls and k_blind_rotate_pairs_k2 / k_blind_rotate_glwe)."""
     from tfhe_fbs_map_amd import ExecConfig
-    from tests.helpers import toy_k2
+    from tests.helpers import toy_glwe
     env, boots = random_program(seed)
     if boots == 0:
         pytest.skip("generator produced no bootstrap")
@@ -75,7 +75,7 @@ def test_random_program(seed, k):
     buf = io.StringIO()
     env.print(os=buf, show_outputs=True)
     expect = lut_oracle.eval_fbs_text(buf.getvalue(), ins)
-    cfg = ExecConfig(fbs_size=P, seed=1, reduced_noise=True) if k == 1 else ExecConfig(fbs_size=P, seed=1, params=toy_k2(P, n=40))
+    cfg = ExecConfig(fbs_size=P, seed=1, reduced_noise=True) if k == 1 else ExecConfig(fbs_size=P, seed=1, params=toy_glwe(k, P, n=40))
     got = env.eval(ins, config=cfg)
     assert cfg.last_choice["params"].k == k
     assert_outputs_equal(got, {name: (int(v) if np.ndim(v) == 0 else np.asarray(v, np.int64)) for name, v in expect.items()})
